@@ -1,0 +1,153 @@
+/* azsp.h -- C ABI of libazsp.so, the MI355X-native self-play episode generator.
+ *
+ * The reference (pierreveron/alphazero-implementation) is pure Python and has no FFI; this header
+ * is the boundary a ctypes binding sits on (INTEGRATION.md shows the stub).  Every entry point
+ * names the reference interface it stands behind (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every buffer it passes in; nothing is retained after
+ *     the call returns except the evaluator callback and its user pointer.
+ *   - return value: 0 = ok, < 0 = error code; azsp_last_error() gives the message of the last
+ *     failing call on the calling thread.  Nothing throws across the ABI.
+ *   - one engine = one HIP device + one private non-blocking HIP stream.  Calls on one engine must
+ *     be serialised by the caller; different engines may be used from different threads (the
+ *     reference runs generation on a daemon thread next to training:
+ *     src/alphazero_less_simple/core/training/datamodule.py:19-47,111-117).
+ *   - boards cross the ABI in the reference's own encoding, narrowed to int8: row-major cells,
+ *     row 0 = top, +1 = side to move ("canonical", src/alphazero_simple/connect4_game.py:100-101),
+ *     -1 = opponent, 0 = empty.
+ */
+#ifndef AZSP_H
+#define AZSP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZSP_ABI_VERSION 1
+
+typedef struct azsp_engine azsp_engine;
+
+/* Game plugin ids: device-side traits standing in for BaseGame subclasses
+ * (src/alphazero_simple/base_game.py:6-62). */
+enum { AZSP_GAME_CONNECT4 = 0,   /* src/alphazero_simple/connect4_game.py:6-101 */
+       AZSP_GAME_CONNECT2 = 1 }; /* src/alphazero_simple/connect2_game.py:6-80  */
+
+/* Evaluator kinds: what stands behind BaseModel.predict (src/alphazero_simple/base_model.py:52-58). */
+enum { AZSP_EVAL_RESNET = 0,  /* on-device fp32 MFMA forward of ResNet (src/alphazero_simple/resnet.py:30-157) */
+       AZSP_EVAL_HASH   = 1,  /* deterministic integer-hash (P,V); parity-test evaluator            */
+       AZSP_EVAL_HOST   = 2 };/* host callback: any BaseModel.predict; leaves are handed over in slot order */
+
+enum { AZSP_OK = 0, AZSP_ERR_ARG = -1, AZSP_ERR_HIP = -2, AZSP_ERR_STATE = -3, AZSP_ERR_CALLBACK = -4,
+       AZSP_ERR_NOMEM = -5 };
+
+#define AZSP_FLAG_TIMING 1u      /* record HIP events around every kernel class (azsp_get_stats) */
+
+typedef struct azsp_config {
+    uint32_t struct_size;    /* sizeof(azsp_config), for forward compatibility                       */
+    int32_t  game;           /* AZSP_GAME_*                                                           */
+    int32_t  n_slots;        /* concurrent games = AlphaZeroConfig.num_episodes (config.py:11)       */
+    int32_t  n_sims;         /* AlphaZeroConfig.num_simulations (config.py:8-10)                      */
+    int32_t  device;         /* HIP device ordinal                                                    */
+    int32_t  res_blocks;     /* ResNet num_res_blocks (resnet.py:35), 0 if no device net              */
+    int32_t  channels;       /* ResNet num_channels  (resnet.py:36)                                   */
+    uint32_t flags;          /* AZSP_FLAG_*                                                           */
+    uint64_t hash_salt;      /* AZSP_EVAL_HASH only                                                   */
+} azsp_config;
+
+/* Host evaluator: boards int8[n][cells] (canonical) -> p float32[n][n_actions], v float32[n].
+ * Return 0 on success.  Called on the thread that called into the engine. */
+typedef int (*azsp_predict_fn)(void *user, const int8_t *boards, int32_t n, float *p_out, float *v_out);
+
+/* Result of one ply of lock-step play (azsp_play). */
+typedef struct azsp_ply_result {
+    int32_t ply;               /* index of the ply just played                                       */
+    int32_t n_finished;        /* episodes completed (and counted) in this ply                        */
+    int64_t episodes_total;    /* episodes emitted so far by this generation run                      */
+    int64_t samples_total;     /* samples emitted so far                                              */
+    int32_t uniforms_used;     /* how many of the n_slots uniforms the reference would have drawn:
+                                  n_slots, or (last counted slot + 1) in the stopping ply
+                                  (episode_generator.py:84-87 returns inside the slot loop)         */
+    int32_t finished;          /* 1 once episodes_total >= n_slots                                    */
+} azsp_ply_result;
+
+typedef struct azsp_stats {
+    uint64_t plies, rounds;            /* azsp_search calls, simulation rounds                       */
+    uint64_t evals;                    /* boards evaluated by the evaluator (roots + leaves)         */
+    uint64_t terminal_leaves;          /* simulations that ended on a terminal leaf (no evaluation)  */
+    uint64_t infer_launches;           /* launches of the dominant inference kernel                  */
+    double   infer_ms;                 /* sum of their HIP-event durations (AZSP_FLAG_TIMING)        */
+    uint64_t infer_boards;             /* boards those launches evaluated                            */
+    double   select_ms, expand_ms, play_ms;   /* tree kernels, HIP-event sums                        */
+    uint64_t select_launches, expand_launches;
+    uint64_t path_nodes;               /* sum of backup path lengths (for algorithmic bytes)         */
+} azsp_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int  azsp_abi_version(void);
+int  azsp_create(const azsp_config *cfg, azsp_engine **out);
+void azsp_destroy(azsp_engine *e);
+const char *azsp_last_error(void);
+
+/* geometry of the selected game: BaseGame.get_board_size / get_action_size (base_game.py:17-25) */
+int  azsp_game_info(int32_t game, int32_t *rows, int32_t *cols, int32_t *n_actions, int32_t *max_plies);
+
+/* ---- evaluator ------------------------------------------------------------------------------ */
+/* Upload ResNet weights.  `blob` is the float32 concatenation, in this order, of the state_dict
+ * tensors of src/alphazero_simple/resnet.py:44-72 (each tensor row-major as PyTorch stores it):
+ *   input_conv.0.{weight,bias}, input_conv.1.{weight,bias,running_mean,running_var},
+ *   for i in blocks: residual_blocks.i.{conv1.weight,conv1.bias,bn1.weight,bn1.bias,bn1.running_mean,
+ *                    bn1.running_var,conv2.weight,conv2.bias,bn2.weight,bn2.bias,bn2.running_mean,bn2.running_var},
+ *   policy_head.0.{weight,bias}, policy_head.1.{weight,bias,running_mean,running_var}, policy_head.4.{weight,bias},
+ *   value_head.0.{weight,bias},  value_head.1.{weight,bias,running_mean,running_var},  value_head.4.{weight,bias}
+ * Eval-mode BatchNorm (eps 1e-5) is folded into the preceding convolution at upload. */
+int  azsp_load_resnet(azsp_engine *e, const float *blob, size_t n_floats);
+size_t azsp_resnet_blob_floats(int32_t game, int32_t res_blocks, int32_t channels);
+int  azsp_set_evaluator(azsp_engine *e, int32_t kind, azsp_predict_fn fn, void *user);
+
+/* BaseModel.predict (resnet.py:130-157) with the engine's current evaluator. */
+int  azsp_predict(azsp_engine *e, const int8_t *boards, int32_t n, float *p_out, float *v_out);
+
+/* ---- search facade: MCTS.run_batch (src/alphazero_simple/monte_carlo_tree_search.py:111-171) --- */
+/* Searches n (<= n_slots) caller-supplied canonical boards.  Outputs (any may be NULL):
+ *   counts  int32[n][A]   root.children[a].visit_count (0 where no child)
+ *   child_w float [n][A]  root.children[a].value_sum
+ *   prior   double[n][A]  root.children[a].prior (0 where no child)
+ *   root_w  float [n]     root.value_sum          root_n int32[n]  root.visit_count */
+int  azsp_run_batch(azsp_engine *e, const int8_t *boards, int32_t n, int32_t *counts, float *child_w,
+                    double *prior, float *root_w, int32_t *root_n);
+
+/* ---- episode generation: EpisodeGenerator.generate_episodes
+ *      (src/alphazero_less_simple/core/training/episode_generator.py:23-87) --------------------- */
+int  azsp_reset(azsp_engine *e);                       /* :25-29  fresh games in every slot          */
+int  azsp_search(azsp_engine *e);                      /* :31-36  run_batch on the slots' boards     */
+int  azsp_root_counts(azsp_engine *e, int32_t *counts);/* int32[n_slots][A] of the search just run   */
+/* :38-87  pi, sample (one uniform per slot, slot order), apply, terminal test, emit, restart.      */
+int  azsp_play(azsp_engine *e, const double *uniforms, azsp_ply_result *out);
+/* Copy emitted episodes [first, first+n) to host (any pointer may be NULL):
+ *   ep_offset int64[n+1]  sample range of each episode, relative to the first copied sample
+ *   ep_slot int32[n], ep_ply int32[n]   where/when the episode finished
+ *   states  int8 [S][cells]  canonical boards   (Sample.state,  episode.py:11)
+ *   policies double[S][A]                       (Sample.policy, episode.py:12)
+ *   values  int32[S]                            (Sample.value,  episode.py:13)
+ * with S = total samples of those episodes; sample_cap is the capacity of the three sample arrays. */
+int  azsp_fetch_episodes(azsp_engine *e, int64_t first, int64_t n, int64_t *ep_offset, int32_t *ep_slot,
+                         int32_t *ep_ply, int8_t *states, double *policies, int32_t *values,
+                         int64_t sample_cap);
+/* Device-side export for the multi-GPU all-gather: packs the samples of episodes [first, first+n)
+ * into caller-owned DEVICE memory as records of azsp_record_bytes() bytes:
+ *   int8 state[cells] | int8 value | pad to 8 | double policy[A].  Returns the number of records. */
+int64_t azsp_export_records_device(azsp_engine *e, int64_t first, int64_t n, void *dev_dst, int64_t cap_records);
+int32_t azsp_record_bytes(int32_t game);
+
+int  azsp_get_stats(azsp_engine *e, azsp_stats *out);
+int  azsp_reset_stats(azsp_engine *e);
+int  azsp_sync(azsp_engine *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZSP_H */

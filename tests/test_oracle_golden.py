@@ -142,3 +142,81 @@ def test_hash_evaluator_properties():
     b[0, 3] = 1
     p, _ = oz.hash_eval_bits(*rules.to_bits(b), rules.legal_mask_bits(b), 7, 0)
     assert p[3] == 0 and np.all(p[[0, 1, 2, 4, 5, 6]] > 0)
+
+
+# ----------------------------------------------------------------------------------- C oracle
+from oracle import c_oracle as co  # noqa: E402
+
+
+def test_c_oracle_mt19937_matches_numpy():
+    for seed in (0, 1, 12345, 2**31 + 5):
+        np.random.seed(seed)
+        assert np.array_equal(co.mt_uniforms(seed, 1500), np.random.random_sample(1500))
+
+
+def test_c_oracle_hash_eval_matches_python():
+    rng = np.random.RandomState(3)
+    r4, r2 = oz.C4Rules(), oz.C2Rules()
+    for _ in range(300):
+        b = rng.randint(-1, 2, size=(6, 7))
+        p, v = oz.hash_eval_bits(*r4.to_bits(b), r4.legal_mask_bits(b), 7, 77)
+        pc, vc = co.hash_eval("connect4", b, 77)
+        assert np.array_equal(p, pc, equal_nan=True) and v == vc
+    for _ in range(50):
+        b = rng.randint(-1, 2, size=(4,))
+        p, v = oz.hash_eval_bits(*r2.to_bits(b), r2.legal_mask_bits(b), 4, 5)
+        pc, vc = co.hash_eval("connect2", b, 5)
+        assert np.array_equal(p, pc, equal_nan=True) and v == vc
+
+
+def test_c_oracle_run_batch_matches_reference():
+    for run in load("search_hash.json")["runs"]:
+        boards = np.array(run["boards"], dtype=np.int8)
+        out = co.run_batch(run["game"], run["sims"], boards, run["to_plays"], run["salt"])
+        A = out["counts"].shape[1]
+        for i, g in enumerate(run["roots"]):
+            assert out["root_n"][i] == g["n"] and float(out["root_w"][i]) == g["w"]
+            assert out["n_nodes"][i] == g["nodes"]
+            for a in range(A):
+                k = g["kids"].get(str(a))
+                if k is None:
+                    assert out["counts"][i, a] == 0 and out["prior"][i, a] == 0.0
+                else:
+                    assert out["counts"][i, a] == k["n"]
+                    assert float(out["child_w"][i, a]) == k["w"]
+                    assert float(out["prior"][i, a]) == k["prior"]
+
+
+def _check_generate(o, run):
+    assert o["n_episodes"] == run["n"]
+    assert o["next_uniform"] == run["rng_after"]
+    for e, g in enumerate(run["episodes"]):
+        lo, hi = o["ep_offset"][e], o["ep_offset"][e + 1]
+        shape = (-1,) + tuple(o["shape"])
+        assert o["states"][lo:hi].reshape(shape).tolist() == g["states"]
+        assert o["policies"][lo:hi].tolist() == g["policies"]
+        assert o["values"][lo:hi].tolist() == g["values"]
+        assert o["ep_ply"][e] == g["ply"]
+    row = 0
+    for ply in run["plies"]:
+        for slot, act in enumerate(ply["actions"]):
+            assert o["trace_counts"][row].tolist() == ply["counts"][slot]
+            assert o["trace_actions"][row] == act
+            row += 1
+    assert row == o["trace_rows"]
+
+
+def test_c_oracle_generate_matches_reference():
+    for run in load("episodes_hash.json")["runs"]:
+        _check_generate(co.generate(run["game"], run["sims"], run["n"], run["salt"], seed=run["seed"]), run)
+
+
+def test_c_oracle_generate_with_numpy_rng_and_python_evaluator():
+    """Same transcripts through the callback paths (python predict, global numpy RNG)."""
+    run = [r for r in load("episodes_hash.json")["runs"] if r["game"] == "connect4" and r["n"] == 4][0]
+    rules = oz.C4Rules()
+    model = oz.HashModel(rules, run["salt"])
+    np.random.seed(run["seed"])
+    cb = co.make_predict_cb(model.predict, (6, 7), 7)
+    o = co.generate("connect4", run["sims"], run["n"], seed=None, predict_cb=cb, uniform_cb=co.np_uniform_cb())
+    _check_generate(o, run)
