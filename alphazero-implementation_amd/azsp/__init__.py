@@ -1,0 +1,24 @@
+"""azsp -- MI355X-native self-play episode generation behind the plugin surface of
+pierreveron/alphazero-implementation (`BaseGame` / `BaseModel` / `MCTS` / `EpisodeGenerator`)."""
+from .config import AlphaZeroConfig
+from .episode import Episode, Sample
+from .games import BaseGame, Connect2Game, Connect4Game
+
+__all__ = ["AlphaZeroConfig", "Episode", "Sample", "BaseGame", "Connect2Game", "Connect4Game",
+           "BaseModel", "ResNet", "MCTS", "Node", "EpisodeGenerator", "Engine"]
+
+
+def __getattr__(name):          # torch / libazsp are only imported when their classes are used
+    if name in ("BaseModel", "ResNet", "ResBlock"):
+        from . import model
+        return getattr(model, name)
+    if name in ("MCTS", "Node"):
+        from . import mcts
+        return getattr(mcts, name)
+    if name == "EpisodeGenerator":
+        from .episode_generator import EpisodeGenerator
+        return EpisodeGenerator
+    if name == "Engine":
+        from .engine import Engine
+        return Engine
+    raise AttributeError(name)

@@ -1,0 +1,179 @@
+"""Python handle on one libazsp engine (one HIP device, one private stream).  Thin: every method is
+one C-ABI call plus numpy buffer plumbing."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+GAME_IDS = {"connect4": L.GAME_CONNECT4, "connect2": L.GAME_CONNECT2}
+
+
+def game_id_of(game) -> int:
+    """Map a BaseGame instance (or trait name) to its device trait id."""
+    name = game if isinstance(game, str) else getattr(game, "device_trait", None)
+    if name is None:      # duck-typed reference game objects: go by class name
+        name = {"Connect4Game": "connect4", "Connect2Game": "connect2"}.get(type(game).__name__)
+    if name not in GAME_IDS:
+        raise NotImplementedError(
+            f"{type(game).__name__} has no device trait in libazsp (csrc/azsp_games.h); the engine has no CPU fallback")
+    return GAME_IDS[name]
+
+
+def _ptr(a: np.ndarray | None, ty):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+
+
+class Engine:
+    def __init__(self, game, n_slots: int, n_sims: int, *, device: int = 0, res_blocks: int = 0, channels: int = 0,
+                 timing: bool = False, hash_salt: int = 0):
+        self.lib = L.load()
+        self.game_id = game_id_of(game)
+        r, c, a, mp = (C.c_int32() for _ in range(4))
+        L.check(self.lib.azsp_game_info(self.game_id, C.byref(r), C.byref(c), C.byref(a), C.byref(mp)))
+        self.rows, self.cols, self.n_actions, self.max_plies = r.value, c.value, a.value, mp.value
+        self.cells = self.rows * self.cols
+        self.board_shape = (self.rows, self.cols) if self.rows > 1 else (self.cols,)
+        self.n_slots, self.n_sims = int(n_slots), int(n_sims)
+        self.res_blocks, self.channels = int(res_blocks), int(channels)
+        cfg = L.Config(C.sizeof(L.Config), self.game_id, self.n_slots, self.n_sims, int(device), self.res_blocks,
+                       self.channels, L.FLAG_TIMING if timing else 0, int(hash_salt) & (2**64 - 1))
+        h = C.c_void_p()
+        L.check(self.lib.azsp_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._cb = None           # keep the ctypes trampoline alive
+        self._cb_error: BaseException | None = None
+
+    # ---- lifecycle ----------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.azsp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- evaluator ----------------------------------------------------------------------------
+    def load_resnet(self, blob: np.ndarray) -> None:
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        L.check(self.lib.azsp_load_resnet(self._h, _ptr(blob, C.c_float), blob.size))
+        L.check(self.lib.azsp_set_evaluator(self._h, L.EVAL_RESNET, L.PREDICT_FN(), None))
+
+    def use_hash_evaluator(self) -> None:
+        L.check(self.lib.azsp_set_evaluator(self._h, L.EVAL_HASH, L.PREDICT_FN(), None))
+
+    def use_host_evaluator(self, predict: Callable[[list[np.ndarray]], tuple[Sequence, Sequence]]) -> None:
+        """`predict` has the BaseModel.predict signature: list of int boards -> (list p, list v)."""
+        cells, A, shape = self.cells, self.n_actions, self.board_shape
+
+        def tramp(_user, boards, n, p_out, v_out):
+            try:
+                b = np.ctypeslib.as_array(boards, shape=(n, cells)).astype(np.int64)
+                ps, vs = predict([x.reshape(shape) for x in b])
+                np.ctypeslib.as_array(p_out, shape=(n, A))[:] = np.asarray(ps, dtype=np.float32).reshape(n, A)
+                np.ctypeslib.as_array(v_out, shape=(n,))[:] = np.asarray(vs, dtype=np.float32).reshape(n)
+                return 0
+            except BaseException as exc:    # noqa: BLE001  never unwind through C
+                self._cb_error = exc
+                return 1
+
+        self._cb = L.PREDICT_FN(tramp)
+        L.check(self.lib.azsp_set_evaluator(self._h, L.EVAL_HOST, self._cb, None))
+
+    def _check(self, rc: int) -> None:
+        if rc != 0 and self._cb_error is not None:
+            exc, self._cb_error = self._cb_error, None
+            raise exc
+        L.check(rc)
+
+    def _boards_i8(self, boards) -> np.ndarray:
+        b = np.ascontiguousarray(np.asarray(boards), dtype=np.int8)
+        return b.reshape(-1, self.cells)
+
+    def predict(self, boards) -> tuple[np.ndarray, np.ndarray]:
+        b = self._boards_i8(boards)
+        n = b.shape[0]
+        p = np.empty((n, self.n_actions), np.float32)
+        v = np.empty(n, np.float32)
+        self._check(self.lib.azsp_predict(self._h, _ptr(b, C.c_int8), n, _ptr(p, C.c_float), _ptr(v, C.c_float)))
+        return p, v
+
+    # ---- search -------------------------------------------------------------------------------
+    def run_batch(self, boards) -> dict[str, np.ndarray]:
+        b = self._boards_i8(boards)
+        n, A = b.shape[0], self.n_actions
+        out = {"counts": np.empty((n, A), np.int32), "child_w": np.empty((n, A), np.float32),
+               "prior": np.empty((n, A), np.float64), "root_w": np.empty(n, np.float32),
+               "root_n": np.empty(n, np.int32)}
+        self._check(self.lib.azsp_run_batch(self._h, _ptr(b, C.c_int8), n, _ptr(out["counts"], C.c_int32),
+                                            _ptr(out["child_w"], C.c_float), _ptr(out["prior"], C.c_double),
+                                            _ptr(out["root_w"], C.c_float), _ptr(out["root_n"], C.c_int32)))
+        return out
+
+    # ---- episode generation ---------------------------------------------------------------------
+    def reset(self) -> None:
+        self._check(self.lib.azsp_reset(self._h))
+
+    def search(self) -> None:
+        self._check(self.lib.azsp_search(self._h))
+
+    def root_counts(self) -> np.ndarray:
+        out = np.empty((self.n_slots, self.n_actions), np.int32)
+        self._check(self.lib.azsp_root_counts(self._h, _ptr(out, C.c_int32)))
+        return out
+
+    def play(self, uniforms: np.ndarray) -> L.PlyResult:
+        u = np.ascontiguousarray(uniforms, dtype=np.float64)
+        if u.size != self.n_slots:
+            raise ValueError(f"need {self.n_slots} uniforms, got {u.size}")
+        res = L.PlyResult()
+        self._check(self.lib.azsp_play(self._h, _ptr(u, C.c_double), C.byref(res)))
+        return res
+
+    def fetch_episodes(self, first: int, n: int) -> dict[str, np.ndarray]:
+        cap = n * self.max_plies
+        out = {"ep_offset": np.zeros(n + 1, np.int64), "ep_slot": np.zeros(n, np.int32), "ep_ply": np.zeros(n, np.int32),
+               "states": np.empty((cap, self.cells), np.int8), "policies": np.empty((cap, self.n_actions), np.float64),
+               "values": np.empty(cap, np.int32)}
+        self._check(self.lib.azsp_fetch_episodes(self._h, first, n, _ptr(out["ep_offset"], C.c_int64),
+                                                 _ptr(out["ep_slot"], C.c_int32), _ptr(out["ep_ply"], C.c_int32),
+                                                 _ptr(out["states"], C.c_int8), _ptr(out["policies"], C.c_double),
+                                                 _ptr(out["values"], C.c_int32), cap))
+        ns = int(out["ep_offset"][n])
+        for k in ("states", "policies", "values"):
+            out[k] = out[k][:ns]
+        return out
+
+    def export_records_device(self, first: int, n: int, dev_ptr: int, cap_records: int) -> int:
+        got = self.lib.azsp_export_records_device(self._h, first, n, C.c_void_p(dev_ptr), cap_records)
+        if got < 0:
+            L.check(int(got))
+        return int(got)
+
+    @property
+    def record_bytes(self) -> int:
+        return int(self.lib.azsp_record_bytes(self.game_id))
+
+    # ---- stats --------------------------------------------------------------------------------
+    def stats(self) -> dict[str, float]:
+        s = L.Stats()
+        self._check(self.lib.azsp_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in L.Stats._fields_}
+
+    def reset_stats(self) -> None:
+        self._check(self.lib.azsp_reset_stats(self._h))
+
+    def sync(self) -> None:
+        self._check(self.lib.azsp_sync(self._h))

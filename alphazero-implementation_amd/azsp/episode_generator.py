@@ -1,0 +1,69 @@
+"""Drop-in for the reference's self-play driver
+(reference: src/alphazero_less_simple/core/training/episode_generator.py:13-87).
+
+Same constructor (`EpisodeGenerator(*, game, config)`) and the same generator protocol
+(`generate_episodes(model)` yields `Episode`s in (ply, slot) completion order and stops at the
+`config.num_episodes`-th completion), but all `num_episodes` games and their search trees live on
+the GPU: per ply the host only draws the uniforms the reference would draw from the global numpy
+RNG (one per slot, slot order) and collects the episodes that finished."""
+from __future__ import annotations
+
+from typing import Generator
+
+import numpy as np
+
+from .config import AlphaZeroConfig
+from .engine import Engine
+from .episode import Episode, Sample
+from .mcts import configure_engine_for_model, default_device, engine_geometry_for_model
+
+
+class EpisodeGenerator:
+    def __init__(self, *, game, config: AlphaZeroConfig, device: int | None = None, timing: bool = False):
+        self.game = game
+        self.config = config
+        self.device = device
+        self.timing = timing
+        self._engine: Engine | None = None
+        self._engine_key = None
+        self.last_stats: dict | None = None
+
+    def engine_for(self, model) -> Engine:
+        blocks, ch, salt = engine_geometry_for_model(model)
+        key = (self.config.num_episodes, self.config.num_simulations, blocks, ch, salt)
+        if self._engine is None or key != self._engine_key:
+            if self._engine is not None:
+                self._engine.close()
+            dev = default_device() if self.device is None else self.device
+            self._engine = Engine(self.game, self.config.num_episodes, self.config.num_simulations, device=dev,
+                                  res_blocks=blocks, channels=ch, timing=self.timing, hash_salt=salt)
+            self._engine_key = key
+        configure_engine_for_model(self._engine, model)
+        return self._engine
+
+    def generate_episodes(self, model) -> Generator[Episode, None, None]:
+        eng = self.engine_for(model)
+        n = self.config.num_episodes
+        shape = eng.board_shape
+        eng.reset()
+        emitted = 0
+        while True:
+            eng.search()
+            rng_state = np.random.get_state()
+            res = eng.play(np.random.random_sample(n))
+            if res.uniforms_used < n:
+                # the reference returns inside its slot loop at the N-th completion: later slots
+                # of that ply never draw.  Rewind so the global RNG ends where the reference leaves it.
+                np.random.set_state(rng_state)
+                np.random.random_sample(res.uniforms_used)
+            if res.n_finished:
+                out = eng.fetch_episodes(emitted, res.n_finished)
+                states = out["states"].astype(np.int64).reshape((-1,) + shape)
+                off = out["ep_offset"]
+                for e in range(res.n_finished):
+                    yield Episode(samples=[Sample(state=states[k], policy=out["policies"][k], value=int(out["values"][k]))
+                                           for k in range(off[e], off[e + 1])])
+                emitted += res.n_finished
+            if res.finished:
+                self.last_stats = eng.stats()
+                return

@@ -1,0 +1,44 @@
+"""Weight export: ResNet.state_dict() (layout of reference src/alphazero_simple/resnet.py:44-72)
+-> the flat float32 blob azsp_load_resnet expects (order documented in include/azsp.h)."""
+from __future__ import annotations
+
+import numpy as np
+
+_BN = ("weight", "bias", "running_mean", "running_var")
+
+
+def _conv_bn(prefix_conv: str, prefix_bn: str) -> list[str]:
+    return [f"{prefix_conv}.weight", f"{prefix_conv}.bias"] + [f"{prefix_bn}.{k}" for k in _BN]
+
+
+def resnet_key_order(num_res_blocks: int) -> list[str]:
+    keys = _conv_bn("input_conv.0", "input_conv.1")
+    for i in range(num_res_blocks):
+        keys += _conv_bn(f"residual_blocks.{i}.conv1", f"residual_blocks.{i}.bn1")
+        keys += _conv_bn(f"residual_blocks.{i}.conv2", f"residual_blocks.{i}.bn2")
+    keys += _conv_bn("policy_head.0", "policy_head.1") + ["policy_head.4.weight", "policy_head.4.bias"]
+    keys += _conv_bn("value_head.0", "value_head.1") + ["value_head.4.weight", "value_head.4.bias"]
+    return keys
+
+
+def is_resnet_state_dict(sd) -> bool:
+    return all(k in sd for k in ("input_conv.0.weight", "policy_head.4.weight", "value_head.4.weight"))
+
+
+def resnet_blob(model_or_state_dict) -> tuple[np.ndarray, int, int]:
+    """Returns (blob float32[n], num_res_blocks, num_channels)."""
+    sd = model_or_state_dict if isinstance(model_or_state_dict, dict) else model_or_state_dict.state_dict()
+    if not is_resnet_state_dict(sd):
+        raise ValueError("state_dict does not have the ResNet layout (input_conv / residual_blocks / policy_head / value_head)")
+    blocks = 0
+    while f"residual_blocks.{blocks}.conv1.weight" in sd:
+        blocks += 1
+    channels = int(np.asarray(_np(sd["input_conv.0.weight"])).shape[0])
+    parts = [np.ascontiguousarray(_np(sd[k]), dtype=np.float32).reshape(-1) for k in resnet_key_order(blocks)]
+    return np.concatenate(parts), blocks, channels
+
+
+def _np(t):
+    if isinstance(t, np.ndarray):
+        return t
+    return t.detach().cpu().numpy()

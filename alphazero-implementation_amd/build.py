@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Builds csrc/libazsp.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python alphazero-implementation_amd/build.py [--force] [--save-temps]
+
+Tree/engine translation units are compiled with -ffp-contract=off (bit-exact float64/float32
+arithmetic against the reference); the inference kernel keeps the default fused contraction."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(CSRC, "libazsp.so")
+ARCH = "gfx950"
+
+COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-fhip-fp32-correctly-rounded-divide-sqrt",
+          "-fno-gpu-flush-denormals-to-zero", "-Wall", "-Wno-unused-function"]
+UNITS = {
+    "azsp_tree.hip": ["-ffp-contract=off"],
+    "azsp_engine.hip": ["-ffp-contract=off"],
+    "azsp_resnet.hip": [],
+}
+HEADERS = ["azsp_internal.h", "azsp_games.h", os.path.join("..", "..", "include", "azsp.h")]
+
+
+def hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def newer(a: str, b: str) -> bool:
+    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force: bool = False, save_temps: bool = False) -> str:
+    cc = hipcc()
+    objs = []
+    hdr_paths = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    for src, extra in UNITS.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if force or newer(s, o) or any(newer(h, o) for h in hdr_paths):
+            cmd = [cc, *COMMON, *extra, "-c", s, "-o", o]
+            if save_temps:
+                cmd.insert(1, "-save-temps=obj")
+            print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd, cwd=CSRC)
+        objs.append(o)
+    if force or any(newer(o, OUT) for o in objs):
+        cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT, *objs]
+        print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv))

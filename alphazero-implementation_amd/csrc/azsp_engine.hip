@@ -1,0 +1,528 @@
+// Host side of libazsp.so: engine object, HIP resource management, round/ply sequencing and the
+// C ABI declared in include/azsp.h.  No torch, no Python: plain pointers and sizes only.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/azsp.h"
+#include "azsp_internal.h"
+
+using namespace azsp;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail(AZSP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct GameInfo { int rows, cols, A, cells, max_plies; };
+static bool game_info(int game, GameInfo &gi) {
+    switch (game) {
+        case AZSP_GAME_CONNECT4: gi = {Connect4::ROWS, Connect4::COLS, Connect4::A, Connect4::CELLS, Connect4::MAX_PLIES}; return true;
+        case AZSP_GAME_CONNECT2: gi = {Connect2::ROWS, Connect2::COLS, Connect2::A, Connect2::CELLS, Connect2::MAX_PLIES}; return true;
+    }
+    return false;
+}
+
+static void host_cells_to_bits(int game, const int8_t *cells, u64 &m, u64 &t) {
+    if (game == AZSP_GAME_CONNECT4) cells_to_bits<Connect4>(cells, m, t);
+    else cells_to_bits<Connect2>(cells, m, t);
+}
+
+enum { EV_INFER = 0, EV_SELECT = 1, EV_EXPAND = 2, EV_PLAY = 3, EV_KINDS = 4 };
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+struct azsp_engine {
+    azsp_config cfg{};
+    GameInfo gi{};
+    hipStream_t stream = nullptr;
+    View v{};
+    std::vector<void *> allocs;
+    int evaluator = AZSP_EVAL_HASH;
+    azsp_predict_fn cb = nullptr;
+    void *cb_user = nullptr;
+    ResNetDev *net = nullptr;
+    bool net_loaded = false;
+    bool searched = false;
+    // pinned host staging
+    PlyResultDev *h_res = nullptr;
+    int32_t *h_nleaf = nullptr;
+    unsigned long long *h_counters = nullptr;
+    double *d_uniforms = nullptr;
+    int8_t *d_cells = nullptr;      // [n_slots][cells] device staging for the host evaluator
+    u64 *d_tmp_mine = nullptr, *d_tmp_theirs = nullptr;
+    int32_t *d_st_counts = nullptr, *d_st_rn = nullptr;     // root statistics staging
+    float *d_st_w = nullptr, *d_st_rw = nullptr;
+    double *d_st_prior = nullptr;
+    std::vector<int8_t> h_cells;
+    std::vector<float> h_p, h_v, h_p8;
+    std::vector<u64> h_mine, h_theirs;
+    // timing
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    azsp_stats stats{};
+    uint64_t plies = 0;
+};
+
+template <class T>
+static int dev_alloc(azsp_engine *e, T *&p, size_t n) {
+    void *q = nullptr;
+    hipError_t err = hipMalloc(&q, n * sizeof(T) + 64);
+    if (err != hipSuccess) return fail(AZSP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(err));
+    e->allocs.push_back(q);
+    p = (T *)q;
+    return 0;
+}
+#define DEV_ALLOC(ptr, n) do { int _rc = dev_alloc(e, ptr, (size_t)(n)); if (_rc) return _rc; } while (0)
+
+// ---- timing -------------------------------------------------------------------------------------
+static EventPair *ev_begin(azsp_engine *e, int kind) {
+    if (!(e->cfg.flags & AZSP_FLAG_TIMING)) return nullptr;
+    if (e->ev_used == e->ev_pool.size()) {
+        EventPair p{};
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+        e->ev_pool.push_back(p);
+    }
+    EventPair *p = &e->ev_pool[e->ev_used++];
+    p->kind = kind;
+    hipEventRecord(p->a, e->stream);
+    return p;
+}
+static void ev_end(azsp_engine *e, EventPair *p) { if (p) hipEventRecord(p->b, e->stream); }
+
+static void ev_collect(azsp_engine *e) {       // call only after a stream synchronize
+    for (size_t i = 0; i < e->ev_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e->ev_pool[i].a, e->ev_pool[i].b) != hipSuccess) continue;
+        switch (e->ev_pool[i].kind) {
+            case EV_INFER: e->stats.infer_ms += ms; break;
+            case EV_SELECT: e->stats.select_ms += ms; break;
+            case EV_EXPAND: e->stats.expand_ms += ms; break;
+            case EV_PLAY: e->stats.play_ms += ms; break;
+        }
+    }
+    e->ev_used = 0;
+}
+
+static int sync_stream(azsp_engine *e) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    ev_collect(e);
+    return 0;
+}
+
+// ---- evaluation of the compacted leaves ------------------------------------------------------------
+static int evaluate_leaves(azsp_engine *e, int max_leaves) {
+    const int game = e->cfg.game;
+    switch (e->evaluator) {
+        case AZSP_EVAL_HASH:
+            launch_eval_hash(game, e->v, e->cfg.hash_salt, e->stream);
+            return 0;
+        case AZSP_EVAL_RESNET: {
+            if (!e->net || !e->net_loaded) return fail(AZSP_ERR_STATE, "ResNet evaluator selected but no weights loaded (azsp_load_resnet)");
+            EventPair *p = ev_begin(e, EV_INFER);
+            resnet_forward(e->net, game, e->v.leaf_mine, e->v.leaf_theirs, e->v.leaf_slot, e->v.n_leaf, max_leaves,
+                           e->v.eval_p, e->v.eval_v, e->stream);
+            ev_end(e, p);
+            e->stats.infer_launches++;
+            return 0;
+        }
+        case AZSP_EVAL_HOST: {
+            if (!e->cb) return fail(AZSP_ERR_STATE, "host evaluator selected but no callback set");
+            const int A = e->gi.A, cells = e->gi.cells;
+            launch_leaf_cells(game, e->v, e->d_cells, e->stream);
+            HIP_TRY(hipMemcpyAsync(e->h_nleaf, e->v.n_leaf, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            const int m = *e->h_nleaf;
+            if (m <= 0) return 0;
+            HIP_TRY(hipMemcpyAsync(e->h_cells.data(), e->d_cells, (size_t)m * cells, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            if (e->cb(e->cb_user, e->h_cells.data(), m, e->h_p.data(), e->h_v.data()))
+                return fail(AZSP_ERR_CALLBACK, "host evaluator callback reported failure");
+            for (int j = 0; j < m; ++j)
+                for (int a = 0; a < PSTRIDE; ++a) e->h_p8[(size_t)j * PSTRIDE + a] = a < A ? e->h_p[(size_t)j * A + a] : 0.0f;
+            HIP_TRY(hipMemcpyAsync(e->v.eval_p, e->h_p8.data(), (size_t)m * PSTRIDE * sizeof(float), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->v.eval_v, e->h_v.data(), (size_t)m * sizeof(float), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            return 0;
+        }
+    }
+    return fail(AZSP_ERR_ARG, "unknown evaluator kind %d", e->evaluator);
+}
+
+// MCTS.run_batch on the first n_act slots (monte_carlo_tree_search.py:111-171)
+static int search(azsp_engine *e, int n_act) {
+    const int game = e->cfg.game;
+    e->v.n_act = n_act;
+    launch_root_prepare(game, e->v, e->stream);
+    launch_compact(e->v, e->stream);
+    int rc = evaluate_leaves(e, n_act);
+    if (rc) return rc;
+    launch_expand(game, e->v, e->stream);
+    for (int s = 0; s < e->cfg.n_sims; ++s) {
+        EventPair *p = ev_begin(e, EV_SELECT);
+        launch_select(game, e->v, e->stream);
+        launch_compact(e->v, e->stream);
+        ev_end(e, p);
+        e->stats.select_launches++;
+        rc = evaluate_leaves(e, n_act);
+        if (rc) return rc;
+        p = ev_begin(e, EV_EXPAND);
+        launch_expand(game, e->v, e->stream);
+        ev_end(e, p);
+        e->stats.expand_launches++;
+    }
+    e->stats.plies++;
+    e->searched = true;
+    return 0;
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int azsp_abi_version(void) { return AZSP_ABI_VERSION; }
+
+const char *azsp_last_error(void) { return g_err.c_str(); }
+
+int azsp_game_info(int32_t game, int32_t *rows, int32_t *cols, int32_t *n_actions, int32_t *max_plies) {
+    GameInfo gi;
+    if (!game_info(game, gi)) return fail(AZSP_ERR_ARG, "unknown game id %d", game);
+    if (rows) *rows = gi.rows;
+    if (cols) *cols = gi.cols;
+    if (n_actions) *n_actions = gi.A;
+    if (max_plies) *max_plies = gi.max_plies;
+    return 0;
+}
+
+int32_t azsp_record_bytes(int32_t game) {
+    GameInfo gi;
+    if (!game_info(game, gi)) return fail(AZSP_ERR_ARG, "unknown game id %d", game);
+    return ((gi.cells + 1 + 7) / 8) * 8 + 8 * gi.A;
+}
+
+size_t azsp_resnet_blob_floats(int32_t game, int32_t res_blocks, int32_t channels) {
+    return resnet_blob_floats(game, res_blocks, channels);
+}
+
+void azsp_destroy(azsp_engine *e) {
+    if (!e) return;
+    hipSetDevice(e->cfg.device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (auto &p : e->ev_pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    if (e->net) resnet_destroy(e->net);
+    for (void *p : e->allocs) hipFree(p);
+    if (e->h_res) hipHostFree(e->h_res);
+    if (e->h_nleaf) hipHostFree(e->h_nleaf);
+    if (e->h_counters) hipHostFree(e->h_counters);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+static int create_impl(azsp_engine *e) {
+    const azsp_config &c = e->cfg;
+    const GameInfo &gi = e->gi;
+    HIP_TRY(hipSetDevice(c.device));
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    View &v = e->v;
+    const int N = c.n_slots, A = gi.A, S = c.n_sims;
+    v.n_slots = v.n_act = N;
+    v.A = A;
+    v.n_sims = S;
+    v.E = S + 1;
+    v.C = ((1 + A * (S + 1)) + 7) & ~7;
+    v.D = (S + 2 < gi.max_plies + 2) ? S + 2 : gi.max_plies + 2;
+    v.max_plies = gi.max_plies;
+    v.cells = gi.cells;
+    const size_t NC = (size_t)N * v.C, NE = (size_t)N * v.E;
+    DEV_ALLOC(v.cnt, NC); DEV_ALLOC(v.wsum, NC); DEV_ALLOC(v.prior, NC); DEV_ALLOC(v.kids, NC);
+    DEV_ALLOC(v.blk_parent, NE); DEV_ALLOC(v.st_mine, NE); DEV_ALLOC(v.st_theirs, NE);
+    DEV_ALLOC(v.n_blk, N);
+    DEV_ALLOC(v.path, (size_t)N * v.D); DEV_ALLOC(v.path_len, N); DEV_ALLOC(v.leaf_node, N);
+    DEV_ALLOC(v.leaf_mine, N); DEV_ALLOC(v.leaf_theirs, N); DEV_ALLOC(v.pending, N);
+    DEV_ALLOC(v.leaf_slot, N); DEV_ALLOC(v.n_leaf, 4);
+    DEV_ALLOC(v.eval_p, (size_t)N * PSTRIDE); DEV_ALLOC(v.eval_v, N);
+    double *sq = nullptr;
+    DEV_ALLOC(sq, S + 2);
+    v.sqrt_tab = sq;
+    DEV_ALLOC(v.cur_mine, N); DEV_ALLOC(v.cur_theirs, N); DEV_ALLOC(v.cur_len, N);
+    const size_t NH = (size_t)N * gi.max_plies;
+    DEV_ALLOC(v.h_mine, NH); DEV_ALLOC(v.h_theirs, NH); DEV_ALLOC(v.h_counts, NH * LANES);
+    DEV_ALLOC(v.done, N); DEV_ALLOC(v.reward, N); DEV_ALLOC(v.chosen, N); DEV_ALLOC(v.emit_off, N);
+    DEV_ALLOC(v.ep_offset, N + 1); DEV_ALLOC(v.ep_slot, N); DEV_ALLOC(v.ep_ply, N);
+    DEV_ALLOC(v.out_states, NH * gi.cells); DEV_ALLOC(v.out_policies, NH * A); DEV_ALLOC(v.out_values, NH);
+    DEV_ALLOC(v.totals, 4); DEV_ALLOC(v.counters, 8);
+    DEV_ALLOC(e->d_uniforms, N); DEV_ALLOC(e->d_cells, (size_t)N * gi.cells);
+    DEV_ALLOC(e->d_tmp_mine, N); DEV_ALLOC(e->d_tmp_theirs, N);
+    DEV_ALLOC(e->d_st_counts, (size_t)N * A); DEV_ALLOC(e->d_st_w, (size_t)N * A); DEV_ALLOC(e->d_st_prior, (size_t)N * A);
+    DEV_ALLOC(e->d_st_rw, N); DEV_ALLOC(e->d_st_rn, N);
+
+    std::vector<double> tab(S + 2);
+    for (int i = 0; i < S + 2; ++i) tab[i] = sqrt((double)i);     // host libm == Python math.sqrt
+    HIP_TRY(hipMemcpy(sq, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(v.counters, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(v.kids, 0, NC * sizeof(int32_t)));
+    HIP_TRY(hipMemset(v.prior, 0, NC * sizeof(double)));
+    HIP_TRY(hipMemset(v.cnt, 0, NC * sizeof(int32_t)));
+    HIP_TRY(hipMemset(v.wsum, 0, NC * sizeof(float)));
+    HIP_TRY(hipHostMalloc((void **)&e->h_res, sizeof(PlyResultDev), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&e->h_nleaf, 64, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&e->h_counters, 64, hipHostMallocDefault));
+    e->h_cells.resize((size_t)N * gi.cells);
+    e->h_p.resize((size_t)N * A);
+    e->h_v.resize(N);
+    e->h_p8.resize((size_t)N * PSTRIDE);
+    e->h_mine.resize(N);
+    e->h_theirs.resize(N);
+    if (c.res_blocks > 0 && c.channels > 0) {
+        e->net = resnet_create(c.game, c.res_blocks, c.channels);
+        if (!e->net) return fail(AZSP_ERR_ARG, "unsupported ResNet geometry: %d blocks x %d channels", c.res_blocks, c.channels);
+        e->evaluator = AZSP_EVAL_RESNET;
+    }
+    launch_reset_slots(c.game, v, e->stream);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int azsp_create(const azsp_config *cfg, azsp_engine **out) {
+    if (!cfg || !out) return fail(AZSP_ERR_ARG, "null argument");
+    if (cfg->struct_size != sizeof(azsp_config)) return fail(AZSP_ERR_ARG, "azsp_config.struct_size %u != %zu", cfg->struct_size, sizeof(azsp_config));
+    GameInfo gi;
+    if (!game_info(cfg->game, gi)) return fail(AZSP_ERR_ARG, "unknown game id %d", cfg->game);
+    if (cfg->n_slots <= 0 || cfg->n_slots > (1 << 20)) return fail(AZSP_ERR_ARG, "n_slots %d out of range", cfg->n_slots);
+    if (cfg->n_sims < 0 || cfg->n_sims > 65535) return fail(AZSP_ERR_ARG, "n_sims %d out of range", cfg->n_sims);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(AZSP_ERR_HIP, "no HIP device available: libazsp has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(AZSP_ERR_ARG, "device %d out of range (%d devices)", cfg->device, ndev);
+    azsp_engine *e = new azsp_engine();
+    e->cfg = *cfg;
+    e->gi = gi;
+    int rc = create_impl(e);
+    if (rc) { std::string keep = g_err; azsp_destroy(e); g_err = keep; return rc; }
+    *out = e;
+    return 0;
+}
+
+int azsp_set_evaluator(azsp_engine *e, int32_t kind, azsp_predict_fn fn, void *user) {
+    if (!e) return fail(AZSP_ERR_ARG, "null engine");
+    if (kind == AZSP_EVAL_HOST && !fn) return fail(AZSP_ERR_ARG, "AZSP_EVAL_HOST needs a callback");
+    if (kind == AZSP_EVAL_RESNET && !e->net) return fail(AZSP_ERR_STATE, "engine was created without a ResNet geometry");
+    if (kind < 0 || kind > AZSP_EVAL_HOST) return fail(AZSP_ERR_ARG, "unknown evaluator kind %d", kind);
+    e->evaluator = kind;
+    e->cb = fn;
+    e->cb_user = user;
+    return 0;
+}
+
+int azsp_load_resnet(azsp_engine *e, const float *blob, size_t n_floats) {
+    if (!e || !blob) return fail(AZSP_ERR_ARG, "null argument");
+    if (!e->net) return fail(AZSP_ERR_STATE, "engine was created without a ResNet geometry");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const size_t want = resnet_blob_floats(e->cfg.game, e->cfg.res_blocks, e->cfg.channels);
+    if (n_floats != want) return fail(AZSP_ERR_ARG, "weight blob has %zu floats, expected %zu", n_floats, want);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (resnet_load(e->net, blob, n_floats, e->stream)) return fail(AZSP_ERR_HIP, "weight upload failed");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->net_loaded = true;
+    return 0;
+}
+
+int azsp_sync(azsp_engine *e) {
+    if (!e) return fail(AZSP_ERR_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    return sync_stream(e);
+}
+
+static int upload_boards(azsp_engine *e, const int8_t *boards, int n) {
+    for (int i = 0; i < n; ++i) host_cells_to_bits(e->cfg.game, boards + (size_t)i * e->gi.cells, e->h_mine[i], e->h_theirs[i]);
+    HIP_TRY(hipMemcpyAsync(e->d_tmp_mine, e->h_mine.data(), (size_t)n * sizeof(u64), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_tmp_theirs, e->h_theirs.data(), (size_t)n * sizeof(u64), hipMemcpyHostToDevice, e->stream));
+    launch_set_boards(e->cfg.game, e->v, e->d_tmp_mine, e->d_tmp_theirs, n, e->stream);
+    HIP_TRY(hipStreamSynchronize(e->stream));      // h_mine/h_theirs are pageable: copies must finish before reuse
+    return 0;
+}
+
+int azsp_predict(azsp_engine *e, const int8_t *boards, int32_t n, float *p_out, float *v_out) {
+    if (!e || !boards || n < 0) return fail(AZSP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int N = e->cfg.n_slots, A = e->gi.A;
+    for (int lo = 0; lo < n; lo += N) {
+        const int m = (n - lo < N) ? n - lo : N;
+        int rc = upload_boards(e, boards + (size_t)lo * e->gi.cells, m);
+        if (rc) return rc;
+        e->v.n_act = m;
+        launch_root_prepare(e->cfg.game, e->v, e->stream);
+        launch_compact(e->v, e->stream);
+        rc = evaluate_leaves(e, m);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(e->h_p8.data(), e->v.eval_p, (size_t)m * PSTRIDE * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->h_v.data(), e->v.eval_v, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        rc = sync_stream(e);
+        if (rc) return rc;
+        for (int j = 0; j < m; ++j) {
+            if (p_out) for (int a = 0; a < A; ++a) p_out[(size_t)(lo + j) * A + a] = e->h_p8[(size_t)j * PSTRIDE + a];
+            if (v_out) v_out[lo + j] = e->h_v[j];
+        }
+    }
+    e->v.n_act = N;
+    e->searched = false;
+    return 0;
+}
+
+int azsp_run_batch(azsp_engine *e, const int8_t *boards, int32_t n, int32_t *counts, float *child_w, double *prior,
+                   float *root_w, int32_t *root_n) {
+    if (!e || !boards || n <= 0) return fail(AZSP_ERR_ARG, "bad argument");
+    if (n > e->cfg.n_slots) return fail(AZSP_ERR_ARG, "n %d exceeds n_slots %d", n, e->cfg.n_slots);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int A = e->gi.A;
+    int rc = upload_boards(e, boards, n);
+    if (rc) return rc;
+    rc = search(e, n);
+    if (rc) return rc;
+    int32_t *d_counts = e->d_st_counts, *d_rn = e->d_st_rn;
+    float *d_w = e->d_st_w, *d_rw = e->d_st_rw;
+    double *d_prior = e->d_st_prior;
+    launch_root_stats(e->cfg.game, e->v, d_counts, d_w, d_prior, d_rw, d_rn, e->stream);
+    if (counts) HIP_TRY(hipMemcpyAsync(counts, d_counts, (size_t)n * A * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    if (child_w) HIP_TRY(hipMemcpyAsync(child_w, d_w, (size_t)n * A * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (prior) HIP_TRY(hipMemcpyAsync(prior, d_prior, (size_t)n * A * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (root_w) HIP_TRY(hipMemcpyAsync(root_w, d_rw, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (root_n) HIP_TRY(hipMemcpyAsync(root_n, d_rn, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    rc = sync_stream(e);
+    e->v.n_act = e->cfg.n_slots;
+    e->searched = false;          // the slots no longer hold a generation run
+    return rc;
+}
+
+int azsp_reset(azsp_engine *e) {
+    if (!e) return fail(AZSP_ERR_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    e->v.n_act = e->cfg.n_slots;
+    launch_reset_slots(e->cfg.game, e->v, e->stream);
+    e->searched = false;
+    return sync_stream(e);
+}
+
+int azsp_search(azsp_engine *e) {
+    if (!e) return fail(AZSP_ERR_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    return search(e, e->cfg.n_slots);
+}
+
+int azsp_root_counts(azsp_engine *e, int32_t *counts) {
+    if (!e || !counts) return fail(AZSP_ERR_ARG, "null argument");
+    if (!e->searched) return fail(AZSP_ERR_STATE, "azsp_root_counts before azsp_search");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int N = e->cfg.n_slots, A = e->gi.A;
+    int32_t *d_counts = e->d_st_counts;
+    launch_root_stats(e->cfg.game, e->v, d_counts, nullptr, nullptr, nullptr, nullptr, e->stream);
+    HIP_TRY(hipMemcpyAsync(counts, d_counts, (size_t)N * A * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    return sync_stream(e);
+}
+
+int azsp_play(azsp_engine *e, const double *uniforms, azsp_ply_result *out) {
+    if (!e || !uniforms || !out) return fail(AZSP_ERR_ARG, "null argument");
+    if (!e->searched) return fail(AZSP_ERR_STATE, "azsp_play before azsp_search");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int N = e->cfg.n_slots;
+    HIP_TRY(hipMemcpyAsync(e->d_uniforms, uniforms, (size_t)N * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    EventPair *p = ev_begin(e, EV_PLAY);
+    launch_finish(e->cfg.game, e->v, e->d_uniforms, e->stream);
+    launch_emit(e->cfg.game, e->v, e->h_res, e->stream);
+    ev_end(e, p);
+    int rc = sync_stream(e);
+    if (rc) return rc;
+    out->ply = e->h_res->ply;
+    out->n_finished = e->h_res->n_finished;
+    out->episodes_total = e->h_res->episodes_total;
+    out->samples_total = e->h_res->samples_total;
+    out->uniforms_used = e->h_res->uniforms_used;
+    out->finished = e->h_res->finished;
+    e->searched = false;
+    return 0;
+}
+
+int azsp_fetch_episodes(azsp_engine *e, int64_t first, int64_t n, int64_t *ep_offset, int32_t *ep_slot, int32_t *ep_ply,
+                        int8_t *states, double *policies, int32_t *values, int64_t sample_cap) {
+    if (!e || first < 0 || n < 0) return fail(AZSP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (first + n > e->h_res->episodes_total) return fail(AZSP_ERR_ARG, "episodes [%lld,%lld) not emitted yet (have %lld)", (long long)first, (long long)(first + n), (long long)e->h_res->episodes_total);
+    if (n == 0) return 0;
+    std::vector<int64_t> off((size_t)n + 1);
+    HIP_TRY(hipMemcpy(off.data(), e->v.ep_offset + first, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    const int64_t s0 = off[0], ns = off[n] - off[0];
+    if ((states || policies || values) && ns > sample_cap) return fail(AZSP_ERR_ARG, "sample_cap %lld < %lld samples", (long long)sample_cap, (long long)ns);
+    if (ep_offset) for (int64_t i = 0; i <= n; ++i) ep_offset[i] = off[i] - s0;
+    if (ep_slot) HIP_TRY(hipMemcpy(ep_slot, e->v.ep_slot + first, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (ep_ply) HIP_TRY(hipMemcpy(ep_ply, e->v.ep_ply + first, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int A = e->gi.A, cells = e->gi.cells;
+    if (states) HIP_TRY(hipMemcpy(states, e->v.out_states + s0 * cells, (size_t)ns * cells, hipMemcpyDeviceToHost));
+    if (policies) HIP_TRY(hipMemcpy(policies, e->v.out_policies + s0 * A, (size_t)ns * A * sizeof(double), hipMemcpyDeviceToHost));
+    if (values) HIP_TRY(hipMemcpy(values, e->v.out_values + s0, (size_t)ns * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int64_t azsp_export_records_device(azsp_engine *e, int64_t first, int64_t n, void *dev_dst, int64_t cap_records) {
+    if (!e || first < 0 || n < 0 || !dev_dst) return fail(AZSP_ERR_ARG, "bad argument");
+    if (hipSetDevice(e->cfg.device) != hipSuccess) return fail(AZSP_ERR_HIP, "hipSetDevice failed");
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(AZSP_ERR_HIP, "stream sync failed");
+    if (first + n > e->h_res->episodes_total) return fail(AZSP_ERR_ARG, "episodes not emitted yet");
+    if (n == 0) return 0;
+    int64_t off[2];
+    if (hipMemcpy(&off[0], e->v.ep_offset + first, sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&off[1], e->v.ep_offset + first + n, sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(AZSP_ERR_HIP, "ep_offset copy failed");
+    const int64_t ns = off[1] - off[0];
+    if (ns > cap_records) return fail(AZSP_ERR_ARG, "cap_records %lld < %lld", (long long)cap_records, (long long)ns);
+    launch_export_records(e->cfg.game, e->v, off[0], ns, dev_dst, e->stream);
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(AZSP_ERR_HIP, "export kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    return ns;
+}
+
+int azsp_get_stats(azsp_engine *e, azsp_stats *out) {
+    if (!e || !out) return fail(AZSP_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    int rc = sync_stream(e);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(e->h_counters, e->v.counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    e->stats.evals = e->h_counters[0];
+    e->stats.terminal_leaves = e->h_counters[1];
+    e->stats.path_nodes = e->h_counters[2];
+    e->stats.rounds = e->h_counters[3];
+    e->stats.infer_boards = e->evaluator == AZSP_EVAL_RESNET ? e->h_counters[0] : 0;
+    *out = e->stats;
+    return 0;
+}
+
+int azsp_reset_stats(azsp_engine *e) {
+    if (!e) return fail(AZSP_ERR_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    int rc = sync_stream(e);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(e->v.counters, 0, 8 * sizeof(unsigned long long)));
+    e->stats = azsp_stats{};
+    return 0;
+}
+
+}  // extern "C"

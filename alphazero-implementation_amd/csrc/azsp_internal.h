@@ -1,0 +1,103 @@
+// Internal declarations shared by the translation units of libazsp.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "azsp_games.h"
+
+namespace azsp {
+
+constexpr int LANES = 8;     // lanes per game in the tree kernels (one per action, A <= 8)
+constexpr int PSTRIDE = 8;   // floats per policy row in the evaluation buffers
+
+// Device-resident state of one engine.  Structure-of-arrays; every per-node array is [slot][C].
+//
+//   node 0            root
+//   node 1 + e*A + a  child for action a of the e-th expanded node of this tree ("block" e);
+//                     blocks are bump-allocated in expansion order (deterministic).
+//   kids[x]           first child of x (1 + e*A), 0 while x is unexpanded
+//   blk_parent[e]     the node whose children are block e;  st_*[e] = its canonical position
+struct View {
+    int32_t n_act;     // active slots (n_slots, or fewer for azsp_run_batch)
+    int32_t n_slots;
+    int32_t A;         // actions
+    int32_t C;         // node capacity per tree (array stride)
+    int32_t E;         // block capacity per tree = n_sims + 1
+    int32_t D;         // path stride
+    int32_t n_sims;
+    int32_t max_plies; // history capacity per slot
+    int32_t cells;
+
+    // search tree (SoA)
+    int32_t *cnt;       // N  visit_count                       [n_slots][C]
+    float   *wsum;      // W  value_sum (float32, numpy-2 semantics)
+    double  *prior;     // P  prior (float64; 0 = no child, monte_carlo_tree_search.py:87)
+    int32_t *kids;      // first-child index
+    int32_t *blk_parent;    // [n_slots][E]
+    u64     *st_mine, *st_theirs;   // [n_slots][E]
+    int32_t *n_blk;         // [n_slots]
+    // per-round scratch
+    int32_t *path;          // [n_slots][D]  root .. leaf of the current descent
+    int32_t *path_len;      // [n_slots]     0 for a root expansion (no backup)
+    int32_t *leaf_node;     // [n_slots]
+    u64     *leaf_mine, *leaf_theirs;   // [n_slots] canonical position at the leaf
+    uint8_t *pending;       // [n_slots] leaf awaits evaluation
+    int32_t *leaf_slot;     // [n_slots] compacted (slot order) list of pending slots
+    int32_t *n_leaf;        // [1]
+    float   *eval_p;        // [n_slots][PSTRIDE] evaluator output, indexed by compacted leaf
+    float   *eval_v;        // [n_slots]
+    const double *sqrt_tab; // [n_sims + 2] host-computed sqrt(i): bit-identical to math.sqrt
+    // live games
+    u64     *cur_mine, *cur_theirs;     // [n_slots] canonical position (side to move = mine)
+    int32_t *cur_len;                   // [n_slots] plies played in the current game
+    u64     *h_mine, *h_theirs;         // [n_slots][max_plies] history: root positions
+    int32_t *h_counts;                  // [n_slots][max_plies][LANES] root child visit counts
+    uint8_t *done;                      // [n_slots] game ended this ply
+    int8_t  *reward;                    // [n_slots] reward for the side to move at the end
+    int32_t *chosen;                    // [n_slots] action sampled this ply
+    // episode arena
+    int32_t *emit_off;                  // [n_slots] sample offset of the slot's episode, -1 if none
+    int64_t *ep_offset;                 // [n_slots + 1]
+    int32_t *ep_slot, *ep_ply;          // [n_slots]
+    int8_t  *out_states;                // [cap][cells]
+    double  *out_policies;              // [cap][A]
+    int32_t *out_values;                // [cap]
+    int64_t *totals;                    // [0] episodes, [1] samples, [2] ply index
+    // device-side counters: [0] evals, [1] terminal leaves, [2] path nodes, [3] rounds
+    unsigned long long *counters;
+};
+
+struct PlyResultDev {   // mirrors azsp_ply_result; written by k_emit_scan into pinned host memory
+    int32_t ply, n_finished;
+    int64_t episodes_total, samples_total;
+    int32_t uniforms_used, finished;
+};
+
+// launchers (azsp_tree.hip)
+void launch_root_prepare(int game, const View &v, hipStream_t s);
+void launch_select(int game, const View &v, hipStream_t s);
+void launch_compact(const View &v, hipStream_t s);
+void launch_eval_hash(int game, const View &v, uint64_t salt, hipStream_t s);
+void launch_expand(int game, const View &v, hipStream_t s);
+void launch_leaf_cells(int game, const View &v, int8_t *dst, hipStream_t s);
+void launch_finish(int game, const View &v, const double *uniforms, hipStream_t s);
+void launch_emit(int game, const View &v, PlyResultDev *host_result, hipStream_t s);
+void launch_reset_slots(int game, const View &v, hipStream_t s);
+void launch_set_boards(int game, const View &v, const u64 *mine, const u64 *theirs, int n, hipStream_t s);
+void launch_root_stats(int game, const View &v, int32_t *counts, float *child_w, double *prior, float *root_w,
+                       int32_t *root_n, hipStream_t s);
+void launch_export_records(int game, const View &v, int64_t first_sample, int64_t n_samples, void *dst,
+                           hipStream_t s);
+
+// ResNet evaluator (azsp_resnet.hip)
+struct ResNetDev;
+ResNetDev *resnet_create(int game, int blocks, int channels);
+void resnet_destroy(ResNetDev *);
+int resnet_load(ResNetDev *, const float *blob, size_t n_floats, hipStream_t s);   // 0 ok
+size_t resnet_blob_floats(int game, int blocks, int channels);
+// evaluates boards leaf_mine/theirs[leaf_slot[j]] for j < *n_leaf (<= max_leaves) into out_p/out_v
+void resnet_forward(ResNetDev *, int game, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot,
+                    const int32_t *n_leaf, int max_leaves, float *out_p, float *out_v, hipStream_t s);
+double resnet_flops_per_board(const ResNetDev *);
+
+}  // namespace azsp

@@ -1,0 +1,501 @@
+// Batched policy+value inference on gfx950 matrix cores: the whole ResNet tower of
+// src/alphazero_simple/resnet.py:30-157 (stem, residual blocks, policy head, value head, masked
+// softmax, tanh) fused into ONE kernel, fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32.
+//
+// Mapping (one 256-thread workgroup = 4 wavefronts):
+//   * a workgroup owns TB boards = TB*cells rows of the implicit GEMM, padded to 256 rows
+//     (Connect-4: 6 boards x 42 cells = 252 rows).  Wave w owns rows [64w, 64w+64) = 2 MFMA row tiles
+//     and ALL output channels (NT = C/32 column tiles), so A fragments are reused NT times.
+//   * activations never leave the CU: the layer input lives in LDS as act[row][C+1] (row stride
+//     C+1 dwords -> conflict-free ds_read_b32 of one channel across 32 rows), the residual copy
+//     lives in registers in the MFMA C/D layout, and each conv writes its output back over the
+//     same LDS buffer after a barrier.  A 3x3 tap is an LDS row offset; taps that fall off the
+//     board read a shared all-zero row (validity mask precomputed per lane).
+//   * weights (BatchNorm folded on the host at upload) are pre-permuted into the B-fragment order
+//     [tap][k-step][lane][column tile] so that one coalesced 4*NT-byte load per lane feeds NT MFMAs;
+//     they stream from L2 (whole 64-channel tower = 1.2 MB).
+//   * heads: policy 1x1 conv and value 3x3 conv run on the same MFMA path (N padded to 32), their
+//     ReLU outputs go to LDS, the two Linear layers are per-board dot products reduced in a fixed
+//     order, then masked softmax / tanh.  Every board's result is independent of which tile /
+//     row it landed in (batch-invariant), so leaf order does not influence the search.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "azsp_internal.h"
+
+namespace azsp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WG_ROWS = 256;
+constexpr int POL_CH = 32;      // policy head conv channels (resnet.py:57)
+constexpr int VAL_CH = 3;       // value head conv channels  (resnet.py:66)
+constexpr float BN_EPS = 1e-5f;
+
+struct NetGeom {
+    int rows, cols, cells, A;
+    int C, Cp, NT, S;          // channels, padded to 32, column tiles, k-steps per tap (Cp/2)
+    int blocks, TB;            // residual blocks, boards per workgroup
+};
+
+struct ResNetDev {
+    NetGeom g{};
+    int game = 0;
+    float *d_blob = nullptr;   // all permuted parameters
+    size_t blob_floats = 0;
+    // offsets (in floats) into d_blob
+    size_t o_stem_w, o_stem_b, o_conv_w, o_conv_b, o_pol_w, o_pol_b, o_val_w, o_val_b, o_fcp_w, o_fcp_b, o_fcv_w, o_fcv_b;
+    size_t conv_w_stride, conv_b_stride;
+    double flops_per_board = 0;
+};
+
+struct NetParams {
+    const float *stem_w, *stem_b, *conv_w, *conv_b, *pol_w, *pol_b, *val_w, *val_b, *fcp_w, *fcp_b, *fcv_w, *fcv_b;
+    int conv_w_stride, conv_b_stride, blocks;
+};
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void load_w(const float *p, float (&w)[NT]) {
+    if constexpr (NT == 1) { w[0] = p[0]; }
+    else if constexpr (NT == 2) { float2 t = *reinterpret_cast<const float2 *>(p); w[0] = t.x; w[1] = t.y; }
+    else {
+#pragma unroll
+        for (int i = 0; i < NT; i += 4) { float4 t = *reinterpret_cast<const float4 *>(p + i); w[i] = t.x; w[i + 1] = t.y; w[i + 2] = t.z; w[i + 3] = t.w; }
+    }
+}
+
+// One 3x3 (TAPS = 9) or 1x1 (TAPS = 1, centre tap) convolution as implicit GEMM over the LDS-resident
+// activations.  acc[mt][nt] += A(rows of tile mt, K) * B(K, channels of tile nt).
+//   wl   : permuted weights [tap][S][64][NTW]
+//   ridx : per row tile, float index of this lane's row (+ lane>>5) in `act`
+//   vmask: per row tile, 9-bit tap validity
+template <class G, int MT, int NTW, int TAPS, int S>
+__device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *__restrict__ wl, const float *act,
+                                          const int (&ridx)[MT], const uint32_t (&vmask)[MT], int stride, int zero_idx,
+                                          int lane) {
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const int t9 = (TAPS == 9) ? tap : 4;
+        const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+        const float *arow[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            arow[mt] = act + (((vmask[mt] >> t9) & 1u) ? ridx[mt] + (dy * G::COLS + dx) * stride : zero_idx);
+        const float *wt = wl + ((size_t)tap * S * 64 + lane) * NTW;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            float w[NTW];
+            load_w<NTW>(wt + (size_t)s * 64 * NTW, w);
+            float a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = arow[mt][2 * s];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], w[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+}
+
+// C/D layout of v_mfma_f32_32x32x2_f32: register v of lane l holds
+//   row = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5),  col = l & 31
+__device__ __forceinline__ int cd_row(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
+
+template <class G, int NT>
+__global__ __launch_bounds__(256) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
+                                                         const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
+                                                         float *__restrict__ out_p, float *__restrict__ out_v) {
+    constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
+    constexpr int TB = WG_ROWS / CELLS;            // boards per workgroup
+    constexpr int CP = 32 * NT, S = CP / 2, STRIDE = CP + 1, MT = 2;
+    constexpr int ZERO_IDX = WG_ROWS * STRIDE;
+    extern __shared__ float smem[];
+    float *act = smem;                             // [WG_ROWS + 1][STRIDE]
+    float *part = smem + (WG_ROWS + 1) * STRIDE;   // [WG_ROWS][8] FC partial sums, then logits
+
+    const int n_leaf = *n_leaf_p;
+    const int board0 = blockIdx.x * TB;
+    if (board0 >= n_leaf) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+
+    for (int i = tid; i < STRIDE; i += 256) act[ZERO_IDX + i] = 0.0f;
+
+    // ---- per-lane row geometry -------------------------------------------------------------------
+    int ridx[MT];
+    uint32_t vmask[MT];
+    u64 bm[MT], bt[MT];
+    int ry[MT], rx[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int r = wave * 64 + mt * 32 + (lane & 31);
+        const int b = r / CELLS, pos = r % CELLS;
+        const int y = pos / COLS, x = pos % COLS;
+        const bool real = r < TB * CELLS && board0 + b < n_leaf;
+        uint32_t m = 0;
+        if (real)
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (yy >= 0 && yy < ROWS && xx >= 0 && xx < COLS) m |= 1u << t;
+            }
+        vmask[mt] = m;
+        ridx[mt] = r * STRIDE + half;
+        ry[mt] = y;
+        rx[mt] = x;
+        bm[mt] = 0;
+        bt[mt] = 0;
+        if (real) {
+            const int slot = leaf_slot[board0 + b];
+            bm[mt] = mine[slot];
+            bt[mt] = theirs[slot];
+        }
+    }
+
+    f32x16 acc[MT][NT], xres[MT][NT];
+
+    // ---- stem: conv3x3(3 -> C) + BN + ReLU, A fragments generated from the bitboards ---------------
+    // (_states_to_tensor resnet.py:115-128: planes [empty, mine(+1), theirs(-1)]; input_conv :44-48)
+    {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float bias = P.stem_b[nt * 32 + (lane & 31)];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[mt][nt][v] = bias;
+        }
+        for (int s = 0; s < 14; ++s) {
+            const int kk = 2 * s + half;               // K index = tap*3 + plane, 27 real + 1 zero
+            const int tap = kk / 3, plane = kk % 3;
+            float w[NT];
+            load_w<NT>(P.stem_w + ((size_t)s * 64 + lane) * NT, w);
+            float a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float val = 0.0f;
+                if (kk < 27 && ((vmask[mt] >> tap) & 1u)) {
+                    const int yy = ry[mt] + tap / 3 - 1, xx = rx[mt] + tap % 3 - 1;
+                    const int bit = G::bit_of(yy, xx);
+                    const int mi = (int)((bm[mt] >> bit) & 1ull), th = (int)((bt[mt] >> bit) & 1ull);
+                    const int on = plane == 0 ? (1 - mi) * (1 - th) : (plane == 1 ? mi : th);
+                    val = (float)on;
+                }
+                a[mt] = val;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], w[nt], acc[mt][nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float o = fmaxf(acc[mt][nt][v], 0.0f);
+                    xres[mt][nt][v] = o;
+                    act[(wave * 64 + mt * 32 + cd_row(v, lane)) * STRIDE + nt * 32 + (lane & 31)] = o;
+                }
+    }
+    __syncthreads();
+
+    // ---- residual blocks (ResBlock.forward resnet.py:21-27) -----------------------------------------
+    for (int layer = 0; layer < 2 * P.blocks; ++layer) {
+        const bool second = layer & 1;
+        const float *wl = P.conv_w + (size_t)layer * P.conv_w_stride;
+        const float *bl = P.conv_b + (size_t)layer * P.conv_b_stride;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float bias = bl[nt * 32 + (lane & 31)];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[mt][nt][v] = second ? xres[mt][nt][v] + bias : bias;   // x += residual
+        }
+        conv_mfma<G, MT, NT, 9, S>(acc, wl, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
+        __syncthreads();                               // every wave is done reading the layer input
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float o = fmaxf(acc[mt][nt][v], 0.0f);
+                    if (second) xres[mt][nt][v] = o;
+                    act[(wave * 64 + mt * 32 + cd_row(v, lane)) * STRIDE + nt * 32 + (lane & 31)] = o;
+                }
+        __syncthreads();
+    }
+
+    // ---- heads: policy conv1x1(C->32)+BN+ReLU (resnet.py:56-59), value conv3x3(C->3)+BN+ReLU (:65-68)
+    f32x16 accp[MT][1], accv[MT][1];
+    {
+        const float bp = P.pol_b[lane & 31], bv = P.val_b[lane & 31];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { accp[mt][0][v] = bp; accv[mt][0][v] = bv; }
+    }
+    conv_mfma<G, MT, 1, 1, S>(accp, P.pol_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
+    conv_mfma<G, MT, 1, 9, S>(accv, P.val_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
+    __syncthreads();
+    // head activations over the (now dead) tower activations: cols [0,32) policy, [32,35) value
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = wave * 64 + mt * 32 + cd_row(v, lane);
+            act[row * STRIDE + (lane & 31)] = fmaxf(accp[mt][0][v], 0.0f);
+            if ((lane & 31) < VAL_CH) act[row * STRIDE + POL_CH + (lane & 31)] = fmaxf(accv[mt][0][v], 0.0f);
+        }
+    __syncthreads();
+
+    // ---- Linear layers: Flatten is (c, y, x) order (resnet.py:60-61, :69-70) -------------------------
+    // thread r (< TB*CELLS) = one board cell: partial dot products over channels, fixed order
+    if (tid < TB * CELLS) {
+        const int pos = tid % CELLS;
+        float pa[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) pa[o] = 0.0f;
+        const float *hrow = act + tid * STRIDE;
+        for (int c = 0; c < POL_CH; ++c) {
+            const float h = hrow[c];
+            const float4 w0 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8);
+            const float4 w1 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8 + 4);
+            pa[0] = fmaf(h, w0.x, pa[0]); pa[1] = fmaf(h, w0.y, pa[1]); pa[2] = fmaf(h, w0.z, pa[2]); pa[3] = fmaf(h, w0.w, pa[3]);
+            pa[4] = fmaf(h, w1.x, pa[4]); pa[5] = fmaf(h, w1.y, pa[5]); pa[6] = fmaf(h, w1.z, pa[6]);
+        }
+        float pv = 0.0f;
+#pragma unroll
+        for (int c = 0; c < VAL_CH; ++c) pv = fmaf(hrow[POL_CH + c], P.fcv_w[c * CELLS + pos], pv);
+        pa[7] = pv;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) part[tid * 8 + o] = pa[o];
+    }
+    __syncthreads();
+    float *logits = part + WG_ROWS * 8;            // [TB][8]
+    if (tid < TB * 8) {
+        const int b = tid >> 3, o = tid & 7;
+        float sum = 0.0f;
+        for (int pos = 0; pos < CELLS; ++pos) sum += part[(b * CELLS + pos) * 8 + o];
+        logits[tid] = sum + (o < 7 ? (o < A ? P.fcp_b[o] : 0.0f) : P.fcv_b[0]);
+    }
+    __syncthreads();
+    // ---- masked softmax + tanh (ResNet.predict resnet.py:143-151) -----------------------------------
+    if (tid < TB && board0 + tid < n_leaf) {
+        const int j = board0 + tid;
+        const int slot = leaf_slot[j];
+        const uint32_t legal = G::legal_mask(mine[slot], theirs[slot]);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < A; ++a) if ((legal >> a) & 1u) mx = fmaxf(mx, logits[tid * 8 + a]);
+        float ex[A], den = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A; ++a) { ex[a] = ((legal >> a) & 1u) ? expf(logits[tid * 8 + a] - mx) : 0.0f; den += ex[a]; }
+#pragma unroll
+        for (int a = 0; a < PSTRIDE; ++a) out_p[(size_t)j * PSTRIDE + a] = a < A ? ex[a < A ? a : 0] / den : 0.0f;
+        out_v[j] = tanhf(logits[tid * 8 + 7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host: geometry, BN folding, weight permutation
+// ------------------------------------------------------------------------------------------------
+static bool geom_for(int game, int blocks, int channels, NetGeom &g) {
+    // The reference network is Connect-4 only (ResNet.predict hard-codes Connect4Game, resnet.py:135).
+    if (game == 0) { g.rows = Connect4::ROWS; g.cols = Connect4::COLS; g.cells = Connect4::CELLS; g.A = Connect4::A; }
+    else return false;
+    if (blocks < 0 || channels <= 0) return false;
+    g.C = channels;
+    g.Cp = (channels + 31) / 32 * 32;
+    g.NT = g.Cp / 32;
+    if (g.NT != 1 && g.NT != 2 && g.NT != 4) return false;      // 32/64/128 channels after padding
+    g.S = g.Cp / 2;
+    g.blocks = blocks;
+    g.TB = WG_ROWS / g.cells;
+    return true;
+}
+
+size_t resnet_blob_floats(int game, int blocks, int channels) {
+    NetGeom g;
+    if (!geom_for(game, blocks, channels, g)) return 0;
+    const size_t C = g.C, cells = g.cells;
+    size_t n = C * 3 * 9 + C + 4 * C;                               // input_conv.0 + input_conv.1
+    n += (size_t)blocks * 2 * (C * C * 9 + C + 4 * C);              // residual blocks
+    n += POL_CH * C + POL_CH + 4 * POL_CH + (size_t)g.A * POL_CH * cells + g.A;   // policy head
+    n += VAL_CH * C * 9 + VAL_CH + 4 * VAL_CH + VAL_CH * cells + 1;               // value head
+    return n;
+}
+
+struct ConvBN { const float *w, *b, *gamma, *beta, *mean, *var; int oc, ic, k; };
+
+static const float *take(const float *&p, size_t n) { const float *r = p; p += n; return r; }
+static ConvBN take_conv_bn(const float *&p, int oc, int ic, int k) {
+    ConvBN c;
+    c.oc = oc; c.ic = ic; c.k = k;
+    c.w = take(p, (size_t)oc * ic * k * k);
+    c.b = take(p, oc);
+    c.gamma = take(p, oc); c.beta = take(p, oc); c.mean = take(p, oc); c.var = take(p, oc);
+    return c;
+}
+// eval-mode BatchNorm folded into the convolution: y = (conv(x)+b-mean)*gamma/sqrt(var+eps)+beta
+static void fold(const ConvBN &c, std::vector<float> &w, std::vector<float> &b) {
+    const size_t per = (size_t)c.ic * c.k * c.k;
+    w.resize((size_t)c.oc * per);
+    b.resize(c.oc);
+    for (int o = 0; o < c.oc; ++o) {
+        const double s = (double)c.gamma[o] / sqrt((double)c.var[o] + (double)BN_EPS);
+        for (size_t i = 0; i < per; ++i) w[o * per + i] = (float)((double)c.w[o * per + i] * s);
+        b[o] = (float)(((double)c.b[o] - (double)c.mean[o]) * s + (double)c.beta[o]);
+    }
+}
+
+// B-fragment order for a KxK conv: dst[((tap*S + s)*64 + lane)*NTW + nt] = W[oc = nt*32 + (lane&31)][ic = 2s + (lane>>5)][tap]
+static void permute_conv(const std::vector<float> &w, int oc, int ic, int k, int S, int NTW, float *dst) {
+    const int taps = k * k;
+    for (int tap = 0; tap < taps; ++tap)
+        for (int s = 0; s < S; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int o = nt * 32 + (lane & 31), i = 2 * s + (lane >> 5);
+                    float val = 0.0f;
+                    if (o < oc && i < ic) val = w[((size_t)o * ic + i) * taps + tap];
+                    dst[(((size_t)tap * S + s) * 64 + lane) * NTW + nt] = val;
+                }
+}
+
+ResNetDev *resnet_create(int game, int blocks, int channels) {
+    NetGeom g;
+    if (!geom_for(game, blocks, channels, g)) return nullptr;
+    ResNetDev *n = new ResNetDev();
+    n->g = g;
+    n->game = game;
+    size_t off = 0;
+    auto reserve = [&](size_t cnt) { size_t o = off; off += (cnt + 3) & ~(size_t)3; return o; };
+    n->o_stem_w = reserve((size_t)14 * 64 * g.NT);
+    n->o_stem_b = reserve(g.Cp);
+    n->conv_w_stride = ((size_t)9 * g.S * 64 * g.NT + 3) & ~(size_t)3;
+    n->conv_b_stride = g.Cp;
+    n->o_conv_w = reserve(n->conv_w_stride * 2 * blocks);
+    n->o_conv_b = reserve(n->conv_b_stride * 2 * blocks);
+    n->o_pol_w = reserve((size_t)g.S * 64);
+    n->o_pol_b = reserve(32);
+    n->o_val_w = reserve((size_t)9 * g.S * 64);
+    n->o_val_b = reserve(32);
+    n->o_fcp_w = reserve((size_t)POL_CH * g.cells * 8);
+    n->o_fcp_b = reserve(8);
+    n->o_fcv_w = reserve((size_t)VAL_CH * g.cells);
+    n->o_fcv_b = reserve(4);
+    n->blob_floats = off;
+    if (hipMalloc((void **)&n->d_blob, off * sizeof(float)) != hipSuccess) { delete n; return nullptr; }
+    const double C = g.C, cells = g.cells;
+    n->flops_per_board = 2.0 * cells * (3 * 9 * C + 2.0 * blocks * C * C * 9 + C * POL_CH + C * 9 * VAL_CH) +
+                         2.0 * (POL_CH * cells * g.A + VAL_CH * cells);
+    return n;
+}
+
+void resnet_destroy(ResNetDev *n) {
+    if (!n) return;
+    if (n->d_blob) hipFree(n->d_blob);
+    delete n;
+}
+
+double resnet_flops_per_board(const ResNetDev *n) { return n ? n->flops_per_board : 0.0; }
+
+int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s) {
+    const NetGeom &g = n->g;
+    if (n_floats != resnet_blob_floats(n->game, g.blocks, g.C)) return -1;
+    std::vector<float> host(n->blob_floats, 0.0f), w, b;
+    const float *p = blob;
+    // stem: K index kk = tap*3 + plane
+    {
+        ConvBN c = take_conv_bn(p, g.C, 3, 3);
+        fold(c, w, b);
+        float *dst = host.data() + n->o_stem_w;
+        for (int sidx = 0; sidx < 14; ++sidx)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int nt = 0; nt < g.NT; ++nt) {
+                    const int kk = 2 * sidx + (lane >> 5), o = nt * 32 + (lane & 31);
+                    float val = 0.0f;
+                    if (kk < 27 && o < g.C) val = w[((size_t)o * 3 + kk % 3) * 9 + kk / 3];
+                    dst[((size_t)sidx * 64 + lane) * g.NT + nt] = val;
+                }
+        for (int o = 0; o < g.C; ++o) host[n->o_stem_b + o] = b[o];
+    }
+    for (int l = 0; l < 2 * g.blocks; ++l) {
+        ConvBN c = take_conv_bn(p, g.C, g.C, 3);
+        fold(c, w, b);
+        permute_conv(w, g.C, g.C, 3, g.S, g.NT, host.data() + n->o_conv_w + (size_t)l * n->conv_w_stride);
+        for (int o = 0; o < g.C; ++o) host[n->o_conv_b + (size_t)l * n->conv_b_stride + o] = b[o];
+    }
+    {
+        ConvBN c = take_conv_bn(p, POL_CH, g.C, 1);
+        fold(c, w, b);
+        permute_conv(w, POL_CH, g.C, 1, g.S, 1, host.data() + n->o_pol_w);
+        for (int o = 0; o < POL_CH; ++o) host[n->o_pol_b + o] = b[o];
+        const float *fw = take(p, (size_t)g.A * POL_CH * g.cells), *fb = take(p, g.A);
+        for (int c2 = 0; c2 < POL_CH; ++c2)
+            for (int pos = 0; pos < g.cells; ++pos)
+                for (int o = 0; o < g.A; ++o)
+                    host[n->o_fcp_w + ((size_t)c2 * g.cells + pos) * 8 + o] = fw[(size_t)o * POL_CH * g.cells + (size_t)c2 * g.cells + pos];
+        for (int o = 0; o < g.A; ++o) host[n->o_fcp_b + o] = fb[o];
+    }
+    {
+        ConvBN c = take_conv_bn(p, VAL_CH, g.C, 3);
+        fold(c, w, b);
+        permute_conv(w, VAL_CH, g.C, 3, g.S, 1, host.data() + n->o_val_w);
+        for (int o = 0; o < VAL_CH; ++o) host[n->o_val_b + o] = b[o];
+        const float *fw = take(p, (size_t)VAL_CH * g.cells), *fb = take(p, 1);
+        for (int i = 0; i < VAL_CH * g.cells; ++i) host[n->o_fcv_w + i] = fw[i];
+        host[n->o_fcv_b] = fb[0];
+    }
+    if ((size_t)(p - blob) != n_floats) return -2;
+    if (hipMemcpyAsync(n->d_blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return -3;
+    if (hipStreamSynchronize(s) != hipSuccess) return -4;
+    return 0;
+}
+
+template <class G, int NT>
+static void launch_forward(const ResNetDev *n, const NetParams &P, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot,
+                           const int32_t *n_leaf, int max_leaves, float *out_p, float *out_v, hipStream_t s) {
+    constexpr int TB = WG_ROWS / G::CELLS;
+    constexpr int STRIDE = 32 * NT + 1;
+    const size_t lds = ((size_t)(WG_ROWS + 1) * STRIDE + WG_ROWS * 8 + TB * 8 + 8) * sizeof(float);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[dev] = true;
+    }
+    const int grid = (max_leaves + TB - 1) / TB;
+    hipLaunchKernelGGL((k_resnet_forward<G, NT>), dim3(grid), dim3(256), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
+    (void)n;
+}
+
+void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
+                    int max_leaves, float *out_p, float *out_v, hipStream_t s) {
+    NetParams P;
+    const float *d = n->d_blob;
+    P.stem_w = d + n->o_stem_w; P.stem_b = d + n->o_stem_b;
+    P.conv_w = d + n->o_conv_w; P.conv_b = d + n->o_conv_b;
+    P.pol_w = d + n->o_pol_w; P.pol_b = d + n->o_pol_b;
+    P.val_w = d + n->o_val_w; P.val_b = d + n->o_val_b;
+    P.fcp_w = d + n->o_fcp_w; P.fcp_b = d + n->o_fcp_b;
+    P.fcv_w = d + n->o_fcv_w; P.fcv_b = d + n->o_fcv_b;
+    P.conv_w_stride = (int)n->conv_w_stride;
+    P.conv_b_stride = (int)n->conv_b_stride;
+    P.blocks = n->g.blocks;
+#define FWD(GT, NTV) launch_forward<GT, NTV>(n, P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
+    (void)game;
+    if (n->g.NT == 1) FWD(Connect4, 1); else if (n->g.NT == 2) FWD(Connect4, 2); else FWD(Connect4, 4);
+#undef FWD
+}
+
+}  // namespace azsp

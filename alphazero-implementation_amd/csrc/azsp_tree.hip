@@ -1,0 +1,512 @@
+// Tree kernels of the self-play engine (gfx950).  Compiled with -ffp-contract=off: every float64 /
+// float32 operation below must round exactly like the reference's numpy/Python arithmetic.
+//
+// Thread mapping: 8 lanes per game (one lane per action), 8 games per 64-lane wavefront, one
+// wavefront per workgroup.  Lanes of a game cooperate with width-8 shuffles; the descent path of
+// each game is staged in LDS and flushed to HBM for the expand/backup kernel.
+//
+// Reference functions restated (src/alphazero_simple/monte_carlo_tree_search.py unless noted):
+//   k_select        ucb_score :11-22, Node.select_child :63-78, descent + leaf step :129-152,
+//                   terminal backup :150-152 -> MCTS.backpropagate :214-223
+//   k_expand        mask/renormalise :119-121,:165-167, Node.expand :80-90, backpropagate :214-223
+//   k_root_prepare  run_batch root section :112-123 (root value discarded)
+//   k_finish        src/alphazero_less_simple/core/training/episode_generator.py:38-59 and
+//                   Node.select_action(temperature=1) :43-61 (np.random.choice = cumsum, normalise,
+//                   searchsorted side='right' on one uniform double)
+//   k_emit_*        episode_generator.py:61-87 (z sign rule, slot restart, first-N-completions stop)
+#include "azsp_internal.h"
+
+namespace azsp {
+
+#define GAME_SWITCH(game, CALL)                      \
+    switch (game) {                                  \
+        case 0: { using G = Connect4; CALL; } break; \
+        case 1: { using G = Connect2; CALL; } break; \
+        default: break;                              \
+    }
+
+static inline int groups_grid(int n_games) { return (n_games * LANES + 63) / 64; }
+
+__device__ __forceinline__ double shfl8_d(double x, int src) { return __shfl(x, src, LANES); }
+__device__ __forceinline__ int shfl8_i(int x, int src) { return __shfl(x, src, LANES); }
+
+// ------------------------------------------------------------------------------------------------
+// root preparation: fresh tree per slot, root queued for evaluation (no backup: path_len = 0)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_root_prepare(View v) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= v.n_act) return;
+    size_t base = (size_t)g * v.C;
+    v.cnt[base] = 0;
+    v.wsum[base] = 0.0f;
+    v.kids[base] = 0;
+    v.prior[base] = 0.0;
+    v.n_blk[g] = 0;
+    v.path_len[g] = 0;
+    v.leaf_node[g] = 0;
+    v.leaf_mine[g] = v.cur_mine[g];
+    v.leaf_theirs[g] = v.cur_theirs[g];
+    v.pending[g] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// selection: PUCT descent to the first unexpanded node, leaf step, terminal test
+// ------------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(64) void k_select(View v) {
+    constexpr int A = G::A;
+    static_assert(A <= LANES, "one lane per action");
+    extern __shared__ int s_path[];                 // [8 games][D]
+    const int lane = threadIdx.x & (LANES - 1);
+    const int grp = threadIdx.x >> 3;
+    const int g = blockIdx.x * (64 / LANES) + grp;
+    const bool live = g < v.n_act;
+    const size_t base = (size_t)(live ? g : 0) * v.C;
+    int *my_path = s_path + grp * v.D;
+
+    int node = 0, depth = 0, parent_fc = 0, action = 0;
+    bool walking = live;
+    while (true) {
+        int fc = walking ? v.kids[base + node] : 0;
+        walking = walking && fc != 0;               // Node.expanded() :35-36
+        if (!__any(walking)) break;
+        double score = -INFINITY;
+        if (walking && lane < A) {
+            const int child = fc + lane;
+            const double p = v.prior[base + child];
+            if (p != 0.0) {                         // a child exists only where prob != 0  (:87)
+                const int n = v.cnt[base + child];
+                const int np_ = v.cnt[base + node];
+                // ucb_score :11-22.  (prior * sqrt(N_parent)) / (n + 1) in float64;
+                // -(W / n) in float32 (numpy 2.x), promoted for the sum.
+                const double u = (p * v.sqrt_tab[np_]) / (double)(n + 1);
+                double q = 0.0;
+                if (n > 0) {
+                    const float qf = v.wsum[base + child] / (float)n;
+                    q = (double)(-qf);
+                }
+                score = q + u;
+                if (!(score == score)) score = -INFINITY;   // NaN is never '>' the running best
+            }
+        }
+        // argmax, strict '>' in ascending action order == maximum score, lowest action on ties
+        int best = lane;
+#pragma unroll
+        for (int m = 1; m < LANES; m <<= 1) {
+            const double so = __shfl_xor(score, m, LANES);
+            const int bo = __shfl_xor(best, m, LANES);
+            if (so > score || (so == score && bo < best)) { score = so; best = bo; }
+        }
+        if (walking) {
+            if (lane == 0) my_path[depth] = node;
+            parent_fc = fc;
+            action = best;
+            node = fc + best;
+            ++depth;
+        }
+    }
+    if (live && lane == 0) my_path[depth] = node;
+    const int L = depth + 1;                        // nodes on the path, root .. leaf
+    __syncthreads();                                // one wave per block: orders the LDS path writes
+
+    // leaf step (:135-145): parent's position + action, flip perspective, terminal test
+    int term = TERM_NONE;
+    u64 nm = 0, nt = 0;
+    if (live) {
+        const int e = (parent_fc - 1) / A;
+        const u64 pm = v.st_mine[(size_t)g * v.E + e];
+        const u64 pt = v.st_theirs[(size_t)g * v.E + e];
+        G::play(pm, pt, action, nm, nt);
+        term = G::terminal(nm, nt);
+    }
+    if (live && term != TERM_NONE) {
+        // terminal leaf: never expanded, value in {+1,-1,0}; backpropagate :214-223.  The sign
+        // alternates with distance from the leaf (to_play alternates level by level).
+        const float val = (float)term;
+        for (int k = lane; k < L; k += LANES) {
+            const int nd = my_path[L - 1 - k];
+            const float dv = (k & 1) ? -val : val;
+            v.wsum[base + nd] = v.wsum[base + nd] + dv;
+            v.cnt[base + nd] = v.cnt[base + nd] + 1;
+        }
+        if (lane == 0) {
+            v.pending[g] = 0;
+            atomicAdd(&v.counters[1], 1ull);
+            atomicAdd(&v.counters[2], (unsigned long long)L);
+        }
+    } else if (live) {
+        for (int k = lane; k < L; k += LANES) v.path[(size_t)g * v.D + k] = my_path[k];
+        if (lane == 0) {
+            v.pending[g] = 1;
+            v.path_len[g] = L;
+            v.leaf_node[g] = node;
+            v.leaf_mine[g] = nm;
+            v.leaf_theirs[g] = nt;
+            atomicAdd(&v.counters[2], (unsigned long long)L);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stable (slot-order) compaction of the pending leaves; one workgroup
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_compact(View v) {
+    __shared__ int s_sum[1024];
+    const int t = threadIdx.x;
+    const int per = (v.n_act + 1023) / 1024;
+    const int lo = t * per, hi = min(lo + per, v.n_act);
+    int c = 0;
+    for (int g = lo; g < hi; ++g) c += v.pending[g];
+    s_sum[t] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {      // Hillis-Steele inclusive scan
+        int x = (t >= off) ? s_sum[t - off] : 0;
+        __syncthreads();
+        s_sum[t] += x;
+        __syncthreads();
+    }
+    int pos = s_sum[t] - c;
+    for (int g = lo; g < hi; ++g)
+        if (v.pending[g]) v.leaf_slot[pos++] = g;
+    if (t == 1023) {
+        v.n_leaf[0] = s_sum[1023];
+        atomicAdd(&v.counters[0], (unsigned long long)s_sum[1023]);
+        atomicAdd(&v.counters[3], 1ull);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// hash evaluator
+// ------------------------------------------------------------------------------------------------
+template <class G>
+__global__ void k_eval_hash(View v, uint64_t salt) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= v.n_leaf[0]) return;
+    const int g = v.leaf_slot[j];
+    const u64 m = v.leaf_mine[g], t = v.leaf_theirs[g];
+    float p[G::A];
+    const float val = hash_eval<G::A>(m, t, G::legal_mask(m, t), salt, p);
+#pragma unroll
+    for (int a = 0; a < PSTRIDE; ++a) v.eval_p[(size_t)j * PSTRIDE + a] = a < G::A ? p[a < G::A ? a : 0] : 0.0f;
+    v.eval_v[j] = val;
+}
+
+// ------------------------------------------------------------------------------------------------
+// expansion + backup of the evaluated leaves
+// ------------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(64) void k_expand(View v) {
+    constexpr int A = G::A;
+    const int lane = threadIdx.x & (LANES - 1);
+    const int j = (blockIdx.x * 64 + threadIdx.x) >> 3;
+    const bool live = j < v.n_leaf[0];
+    const int g = live ? v.leaf_slot[j] : 0;
+    const size_t base = (size_t)g * v.C;
+    const u64 mine = v.leaf_mine[g], theirs = v.leaf_theirs[g];
+    const uint32_t legal = G::legal_mask(mine, theirs);
+
+    // action_probs * valid_moves -> float64 ; /= np.sum (sequential for < 8 elements)
+    double pa = 0.0;
+    if (live && lane < A) pa = (double)v.eval_p[(size_t)j * PSTRIDE + lane] * (double)((legal >> lane) & 1u);
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < A; ++a) s = s + shfl8_d(pa, a);
+    const double pr = pa / s;
+    if (!live) return;
+
+    const int node = v.leaf_node[g];
+    const int e = v.n_blk[g];                       // read by all 8 lanes before lane 0 bumps it
+    const int fc = 1 + e * A;
+    if (lane < A) {                                 // Node.expand :80-90
+        v.cnt[base + fc + lane] = 0;
+        v.wsum[base + fc + lane] = 0.0f;
+        v.prior[base + fc + lane] = pr;
+        v.kids[base + fc + lane] = 0;
+    }
+    const int L = v.path_len[g];
+    const float val = v.eval_v[j];
+    for (int k = lane; k < L; k += LANES) {         // backpropagate :214-223
+        const int nd = v.path[(size_t)g * v.D + (L - 1 - k)];
+        const float dv = (k & 1) ? -val : val;
+        v.wsum[base + nd] = v.wsum[base + nd] + dv;
+        v.cnt[base + nd] = v.cnt[base + nd] + 1;
+    }
+    __syncthreads();                                // all lanes have read n_blk
+    if (lane == 0) {
+        v.kids[base + node] = fc;
+        v.blk_parent[(size_t)g * v.E + e] = node;
+        v.st_mine[(size_t)g * v.E + e] = mine;
+        v.st_theirs[(size_t)g * v.E + e] = theirs;
+        v.n_blk[g] = e + 1;
+        v.pending[g] = 0;
+    }
+}
+
+// compacted leaf positions as int8 cells, for the host evaluator
+template <class G>
+__global__ void k_leaf_cells(View v, int8_t *dst) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= v.n_leaf[0]) return;
+    const int g = v.leaf_slot[j];
+    bits_to_cells<G>(v.leaf_mine[g], v.leaf_theirs[g], dst + (size_t)j * G::CELLS);
+}
+
+// ------------------------------------------------------------------------------------------------
+// end of ply: pi, sample, apply, terminal test
+// ------------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(64) void k_finish(View v, const double *uniforms) {
+    constexpr int A = G::A;
+    const int lane = threadIdx.x & (LANES - 1);
+    const int g = (blockIdx.x * 64 + threadIdx.x) >> 3;
+    const bool live = g < v.n_act;
+    const size_t base = (size_t)(live ? g : 0) * v.C;
+    int c = 0, ex = 0;
+    if (live && lane < A) {
+        ex = v.prior[base + 1 + lane] != 0.0;       // root.children keys
+        c = ex ? v.cnt[base + 1 + lane] : 0;
+    }
+    int cs[A], exs[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) { cs[a] = shfl8_i(c, a); exs[a] = shfl8_i(ex, a); }
+    if (!live) return;
+
+    const int len = v.cur_len[g];
+    const size_t h = (size_t)g * v.max_plies + len;
+    v.h_counts[h * LANES + lane] = c;               // episode_generator.py:45-52 (pi = counts / sum at emit)
+    const u64 mine = v.cur_mine[g], theirs = v.cur_theirs[g];
+    if (lane == 0) { v.h_mine[h] = mine; v.h_theirs[h] = theirs; }
+
+    // Node.select_action(temperature=1) :43-61
+    double tot = 0.0;
+#pragma unroll
+    for (int a = 0; a < A; ++a) if (exs[a]) tot = tot + (double)cs[a];      // builtin sum(): 0 + d0 + ...
+    double cdf[A], run = 0.0;
+#pragma unroll
+    for (int a = 0; a < A; ++a) { if (exs[a]) run = run + (double)cs[a] / tot; cdf[a] = run; }   // np.cumsum
+    const double last = run;
+    const double u = uniforms[g];
+    int act = -1, last_ex = 0;
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+        if (exs[a]) {
+            last_ex = a;
+            if (act < 0 && !(cdf[a] / last <= u)) act = a;                  // searchsorted(side='right')
+        }
+    if (act < 0) act = last_ex;
+
+    u64 nm, nt;
+    G::play(mine, theirs, act, nm, nt);             // episode_generator.py:55-58
+    const int term = G::terminal(nm, nt);           // :59 reward for the player now to move
+    if (lane == 0) {
+        v.cur_mine[g] = nm;
+        v.cur_theirs[g] = nt;
+        v.cur_len[g] = len + 1;
+        v.chosen[g] = act;
+        v.done[g] = term != TERM_NONE;
+        v.reward[g] = (int8_t)(term == TERM_NONE ? 0 : term);
+    }
+}
+
+// first-N-completions bookkeeping (episode_generator.py:78-87); one workgroup, slot order
+__global__ __launch_bounds__(1024) void k_emit_scan(View v, PlyResultDev *res) {
+    __shared__ int s_ep[1024];
+    __shared__ int s_sm[1024];
+    __shared__ int s_last;
+    const int t = threadIdx.x;
+    const int per = (v.n_act + 1023) / 1024;
+    const int lo = t * per, hi = min(lo + per, v.n_act);
+    const long long ep0 = v.totals[0], sm0 = v.totals[1];
+    const long long remaining = (long long)v.n_slots - ep0;
+    if (t == 0) s_last = -1;
+    int ce = 0;
+    for (int g = lo; g < hi; ++g) ce += v.done[g];
+    s_ep[t] = ce;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int x = (t >= off) ? s_ep[t - off] : 0;
+        __syncthreads();
+        s_ep[t] += x;
+        __syncthreads();
+    }
+    int rank = s_ep[t] - ce;                        // completions before this thread's first slot
+    int cs = 0;
+    for (int g = lo; g < hi; ++g)
+        if (v.done[g]) { if (rank < remaining) cs += v.cur_len[g]; ++rank; }
+    s_sm[t] = cs;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int x = (t >= off) ? s_sm[t - off] : 0;
+        __syncthreads();
+        s_sm[t] += x;
+        __syncthreads();
+    }
+    rank = s_ep[t] - ce;
+    long long soff = sm0 + s_sm[t] - cs;
+    for (int g = lo; g < hi; ++g) {
+        int off = -1;
+        if (v.done[g]) {
+            if (rank < remaining) {
+                off = (int)soff;
+                const long long e = ep0 + rank;
+                v.ep_slot[e] = g;
+                v.ep_ply[e] = (int)v.totals[2];
+                v.ep_offset[e + 1] = soff + v.cur_len[g];
+                soff += v.cur_len[g];
+                if (rank == remaining - 1) s_last = g;      // the N-th completion: generation stops here
+            }
+            ++rank;
+        }
+        v.emit_off[g] = off;
+    }
+    __syncthreads();
+    if (t == 1023) {
+        const long long total_done = s_ep[1023];
+        const long long counted = total_done < remaining ? total_done : remaining;
+        const long long ep1 = ep0 + counted, sm1 = sm0 + s_sm[1023];
+        res->ply = (int)v.totals[2];
+        res->n_finished = (int)counted;
+        res->episodes_total = ep1;
+        res->samples_total = sm1;
+        res->finished = ep1 >= v.n_slots;
+        res->uniforms_used = (ep1 >= v.n_slots && s_last >= 0) ? s_last + 1 : v.n_act;
+        v.totals[0] = ep1;
+        v.totals[1] = sm1;
+        v.totals[2] = v.totals[2] + 1;
+    }
+}
+
+// copy finished episodes into the arena and restart their slots
+template <class G>
+__global__ __launch_bounds__(64) void k_emit_copy(View v) {
+    constexpr int A = G::A;
+    const int lane = threadIdx.x & (LANES - 1);
+    const int g = (blockIdx.x * 64 + threadIdx.x) >> 3;
+    if (g >= v.n_act || !v.done[g]) return;
+    const int len = v.cur_len[g];
+    const int off = v.emit_off[g];
+    const int rew = v.reward[g];
+    if (off >= 0) {
+        for (int q = 0; q < len; ++q) {
+            const size_t h = (size_t)g * v.max_plies + q;
+            const int c = v.h_counts[h * LANES + lane];
+            int sum = 0;
+#pragma unroll
+            for (int a = 0; a < A; ++a) sum += shfl8_i(c, a);
+            // pi = counts / np.sum(counts)  (episode_generator.py:45-48): int -> float64 divide
+            if (lane < A) v.out_policies[(size_t)(off + q) * A + lane] = (double)c / (double)sum;
+            const u64 m = v.h_mine[h], t = v.h_theirs[h];
+            for (int cell = lane; cell < G::CELLS; cell += LANES) {
+                const int r = cell / G::COLS, cc = cell % G::COLS;
+                const int b = G::bit_of(r, cc);
+                v.out_states[(size_t)(off + q) * G::CELLS + cell] =
+                    (int8_t)(((m >> b) & 1) ? 1 : (((t >> b) & 1) ? -1 : 0));
+            }
+            // value = reward * (-1)**(hist_player != final_player)  (:73-74); players alternate
+            if (lane == 0) v.out_values[off + q] = ((len - q) & 1) ? -rew : rew;
+        }
+    }
+    if (lane == 0) {                                // :80-82 fresh game in this slot
+        v.cur_mine[g] = 0;
+        v.cur_theirs[g] = 0;
+        v.cur_len[g] = 0;
+    }
+}
+
+__global__ void k_reset_slots(View v) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) { v.totals[0] = 0; v.totals[1] = 0; v.totals[2] = 0; v.ep_offset[0] = 0; }
+    if (g >= v.n_slots) return;
+    v.cur_mine[g] = 0;
+    v.cur_theirs[g] = 0;
+    v.cur_len[g] = 0;
+    v.done[g] = 0;
+    v.pending[g] = 0;
+}
+
+__global__ void k_set_boards(View v, const u64 *mine, const u64 *theirs, int n) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    v.cur_mine[g] = mine[g];
+    v.cur_theirs[g] = theirs[g];
+    v.cur_len[g] = 0;
+}
+
+template <class G>
+__global__ void k_root_stats(View v, int32_t *counts, float *child_w, double *prior, float *root_w, int32_t *root_n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.n_act * G::A) return;
+    const int g = i / G::A, a = i % G::A;
+    const size_t base = (size_t)g * v.C;
+    const double p = v.prior[base + 1 + a];
+    const bool ex = p != 0.0;
+    if (counts) counts[i] = ex ? v.cnt[base + 1 + a] : 0;
+    if (child_w) child_w[i] = ex ? v.wsum[base + 1 + a] : 0.0f;
+    if (prior) prior[i] = ex ? p : 0.0;
+    if (a == 0) {
+        if (root_w) root_w[g] = v.wsum[base];
+        if (root_n) root_n[g] = v.cnt[base];
+    }
+}
+
+// packed records for the multi-GPU all-gather: int8 state[cells] | int8 value | pad to 8 | double policy[A]
+template <class G>
+__global__ void k_export_records(View v, long long first, long long n, unsigned char *dst) {
+    constexpr int HEAD = ((G::CELLS + 1 + 7) / 8) * 8;
+    constexpr int REC = HEAD + 8 * G::A;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned char *r = dst + i * REC;
+    const long long s = first + i;
+    for (int c = 0; c < G::CELLS; ++c) r[c] = (unsigned char)v.out_states[s * G::CELLS + c];
+    r[G::CELLS] = (unsigned char)(int8_t)v.out_values[s];
+    for (int c = G::CELLS + 1; c < HEAD; ++c) r[c] = 0;
+    double *pol = (double *)(r + HEAD);
+    for (int a = 0; a < G::A; ++a) pol[a] = v.out_policies[s * G::A + a];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+void launch_root_prepare(int, const View &v, hipStream_t s) {
+    hipLaunchKernelGGL(k_root_prepare, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v);
+}
+void launch_select(int game, const View &v, hipStream_t s) {
+    const size_t lds = (size_t)(64 / LANES) * v.D * sizeof(int);
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_select<G>, dim3(groups_grid(v.n_act)), dim3(64), lds, s, v));
+}
+void launch_compact(const View &v, hipStream_t s) { hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, v); }
+void launch_eval_hash(int game, const View &v, uint64_t salt, hipStream_t s) {
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_eval_hash<G>, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v, salt));
+}
+void launch_expand(int game, const View &v, hipStream_t s) {
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_expand<G>, dim3(groups_grid(v.n_act)), dim3(64), 0, s, v));
+}
+void launch_leaf_cells(int game, const View &v, int8_t *dst, hipStream_t s) {
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_leaf_cells<G>, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v, dst));
+}
+void launch_finish(int game, const View &v, const double *uniforms, hipStream_t s) {
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_finish<G>, dim3(groups_grid(v.n_act)), dim3(64), 0, s, v, uniforms));
+}
+void launch_emit(int game, const View &v, PlyResultDev *res, hipStream_t s) {
+    hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(1024), 0, s, v, res);
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_emit_copy<G>, dim3(groups_grid(v.n_act)), dim3(64), 0, s, v));
+}
+void launch_reset_slots(int, const View &v, hipStream_t s) {
+    hipLaunchKernelGGL(k_reset_slots, dim3((v.n_slots + 255) / 256), dim3(256), 0, s, v);
+}
+void launch_set_boards(int, const View &v, const u64 *mine, const u64 *theirs, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_set_boards, dim3((n + 255) / 256), dim3(256), 0, s, v, mine, theirs, n);
+}
+void launch_root_stats(int game, const View &v, int32_t *counts, float *child_w, double *prior, float *root_w,
+                       int32_t *root_n, hipStream_t s) {
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_root_stats<G>, dim3((v.n_act * G::A + 255) / 256), dim3(256), 0, s, v,
+                                         counts, child_w, prior, root_w, root_n));
+}
+void launch_export_records(int game, const View &v, int64_t first, int64_t n, void *dst, hipStream_t s) {
+    if (n <= 0) return;
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_export_records<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v,
+                                         (long long)first, (long long)n, (unsigned char *)dst));
+}
+
+}  // namespace azsp

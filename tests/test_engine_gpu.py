@@ -1,0 +1,257 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against the oracle and the golden
+fixtures generated from the reference.  Integer / index / float64 search results must be
+BIT-EXACT; network outputs are compared with the tolerance stated in each test."""
+import numpy as np
+import pytest
+
+from helpers import HashStub, HostOnlyModel, check_episode_invariants, load_json, random_midgame_boards
+from oracle import az_oracle as oz
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def azsp():
+    import azsp as pkg
+    from azsp import _lib
+    _lib.load()
+    return pkg
+
+
+def _engine(azsp, game, n, sims, **kw):
+    from azsp.engine import Engine
+    return Engine(game, n, sims, **kw)
+
+
+# ------------------------------------------------------------------------------------ hash evaluator
+def test_hash_evaluator_bit_exact(azsp):
+    rng = np.random.RandomState(5)
+    rules = oz.C4Rules()
+    boards = random_midgame_boards(rules, rng, 300, 41)
+    with _engine(azsp, "connect4", 128, 1, hash_salt=991) as e:
+        e.use_hash_evaluator()
+        p, v = e.predict(np.stack(boards))
+    for b, pi, vi in zip(boards, p, v):
+        po, vo = oz.hash_eval_bits(*rules.to_bits(b), rules.legal_mask_bits(b), 7, 991)
+        assert np.array_equal(pi, po) and vi == vo
+
+
+# ------------------------------------------------------------------------------------ search
+def _check_run(out, run):
+    A = out["counts"].shape[1]
+    for i, g in enumerate(run["roots"]):
+        assert out["root_n"][i] == g["n"]
+        assert float(out["root_w"][i]) == g["w"]
+        for a in range(A):
+            k = g["kids"].get(str(a))
+            if k is None:
+                assert out["counts"][i, a] == 0 and out["prior"][i, a] == 0.0
+            else:
+                assert out["counts"][i, a] == k["n"], (i, a)
+                assert float(out["child_w"][i, a]) == k["w"], (i, a)
+                assert float(out["prior"][i, a]) == k["prior"], (i, a)
+
+
+def test_run_batch_matches_reference_fixtures(azsp):
+    for run in load_json("search_hash.json")["runs"]:
+        boards = np.array(run["boards"], dtype=np.int8)
+        with _engine(azsp, run["game"], len(boards), run["sims"], hash_salt=run["salt"]) as e:
+            e.use_hash_evaluator()
+            _check_run(e.run_batch(boards), run)
+
+
+def test_mcts_facade_matches_reference_fixtures(azsp):
+    run = [r for r in load_json("search_hash.json")["runs"] if r["game"] == "connect4" and r["sims"] == 100][0]
+    mcts = azsp.MCTS(azsp.Connect4Game(), HashStub("connect4", run["salt"]), run["sims"])
+    roots = mcts.run_batch([np.array(b) for b in run["boards"]], run["to_plays"])
+    for root, g in zip(roots, run["roots"]):
+        assert root.visit_count == g["n"] and float(root.value_sum) == g["w"]
+        assert sorted(root.children) == sorted(int(a) for a in g["kids"])
+        for a, k in g["kids"].items():
+            c = root.children[int(a)]
+            assert c.visit_count == k["n"] and float(c.value_sum) == k["w"] and float(c.prior) == k["prior"]
+        assert root.select_action(0) == max(root.children, key=lambda a: (root.children[a].visit_count, -a))
+    one = mcts.run(np.array(run["boards"][0]), 1)
+    assert one.visit_count == run["roots"][0]["n"]
+
+
+# ------------------------------------------------------------------------------------ episodes
+def _episodes_equal(eps, golden):
+    assert len(eps) == len(golden)
+    for ep, g in zip(eps, golden):
+        assert [s.state.tolist() for s in ep.samples] == g["states"]
+        assert [s.policy.tolist() for s in ep.samples] == g["policies"]
+        assert [s.value for s in ep.samples] == g["values"]
+        assert all(type(s.value) is int for s in ep.samples)
+        assert all(s.state.dtype == np.int64 and s.policy.dtype == np.float64 for s in ep.samples)
+
+
+@pytest.mark.parametrize("model_cls", [HashStub, HostOnlyModel])
+def test_generate_episodes_matches_reference_fixtures(azsp, model_cls):
+    """Drop-in EpisodeGenerator vs transcripts of the reference's generate_episodes: states, pi, z,
+    yield order and the number of RNG draws, with the device evaluator and the host-callback path."""
+    games = {"connect4": azsp.Connect4Game, "connect2": azsp.Connect2Game}
+    for run in load_json("episodes_hash.json")["runs"]:
+        if model_cls is HostOnlyModel and run["n"] * run["sims"] > 1000:
+            continue            # python callback per round: keep the slow path small
+        cfg = azsp.AlphaZeroConfig(batch_size=32, num_iterations=1, num_simulations=run["sims"],
+                                   num_episodes=run["n"], num_iters_for_train_history=1, epochs=1)
+        gen = azsp.EpisodeGenerator(game=games[run["game"]](), config=cfg)
+        np.random.seed(run["seed"])
+        eps = list(gen.generate_episodes(model_cls(run["game"], run["salt"])))
+        assert float(np.random.random_sample()) == run["rng_after"]
+        _episodes_equal(eps, run["episodes"])
+
+
+def test_per_ply_root_counts_match_reference_fixtures(azsp):
+    run = [r for r in load_json("episodes_hash.json")["runs"] if r["game"] == "connect4" and r["n"] == 16][0]
+    np.random.seed(run["seed"])
+    with _engine(azsp, "connect4", run["n"], run["sims"], hash_salt=run["salt"]) as e:
+        e.use_hash_evaluator()
+        e.reset()
+        for ply in run["plies"]:
+            e.search()
+            counts = e.root_counts()
+            used = len(ply["actions"])
+            assert counts[:used].tolist() == ply["counts"][:used]
+            res = e.play(np.random.random_sample(run["n"]))
+            assert res.uniforms_used == used
+        assert res.finished and res.episodes_total == run["n"]
+
+
+@pytest.mark.parametrize("n,sims,seed,salt", [(512, 100, 11, 3), (64, 400, 12, 8), (1, 100, 13, 0), (3, 1, 14, 1)])
+def test_generate_matches_c_oracle_at_larger_sizes(azsp, n, sims, seed, salt):
+    ref = co.generate("connect4", sims, n, salt, seed=seed, trace=False)
+    cfg = azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1)
+    np.random.seed(seed)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg)
+    eps = list(gen.generate_episodes(HashStub("connect4", salt)))
+    assert float(np.random.random_sample()) == ref["next_uniform"]
+    assert len(eps) == n
+    for e, ep in enumerate(eps):
+        lo, hi = ref["ep_offset"][e], ref["ep_offset"][e + 1]
+        assert np.array_equal(np.stack([s.state for s in ep.samples]).reshape(hi - lo, -1), ref["states"][lo:hi])
+        assert np.array_equal(np.stack([s.policy for s in ep.samples]), ref["policies"][lo:hi])
+        assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()
+    st = gen.last_stats
+    assert st["evals"] == ref["stats"][0] and st["terminal_leaves"] == ref["stats"][1]
+    assert st["path_nodes"] == ref["stats"][3]
+
+
+# ------------------------------------------------------------------------------------ network
+def _golden_net(tag):
+    z = np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "resnet_forward.npz"))
+    sd = {k[len(tag) + 4:]: z[k] for k in z.files if k.startswith(f"{tag}_sd/")}
+    return z, sd
+
+
+@pytest.mark.parametrize("tag", ["s", "m"])
+def test_resnet_forward_matches_reference_vectors(azsp, tag):
+    """Fused MFMA tower vs ResNet.predict of the reference on torch-CPU.  fp32 everywhere, different
+    summation order and BN folding -> tolerance 1e-5 absolute on probabilities and tanh values."""
+    from azsp.weights import resnet_blob
+    z, sd = _golden_net(tag)
+    blob, blocks, ch = resnet_blob({k: v for k, v in sd.items() if "num_batches_tracked" not in k})
+    assert [blocks, ch] == z[f"{tag}_arch"].tolist()
+    boards = z["boards"]
+    with _engine(azsp, "connect4", 64, 1, res_blocks=blocks, channels=ch) as e:
+        e.load_resnet(blob)
+        p, v = e.predict(boards)
+        p2, v2 = e.predict(boards[::-1].copy())            # batch-invariance: other order, other tiles
+    assert np.array_equal(p2[::-1], p) and np.array_equal(v2[::-1], v)
+    assert np.all(p[z[f"{tag}_p"] == 0] == 0)               # exact zeros on illegal columns
+    assert np.max(np.abs(p - z[f"{tag}_p"])) < 1e-5
+    assert np.max(np.abs(v - z[f"{tag}_v"])) < 1e-5
+    assert np.all(np.abs(p.sum(axis=1) - 1) < 1e-6)
+
+
+def test_resnet_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp):
+    """End-to-end with the real network: the C oracle runs the reference algorithm on the CPU but asks
+    the DEVICE kernel for (P, V) through the C ABI; the engine runs everything on the GPU.  Both see
+    identical floats, so visit counts, moves, pi and z must be bit-identical."""
+    from azsp.weights import resnet_blob
+    _, sd = _golden_net("m")
+    blob, blocks, ch = resnet_blob({k: v for k, v in sd.items() if "num_batches_tracked" not in k})
+    n, sims, seed = 32, 50, 21
+    with _engine(azsp, "connect4", 64, 1, res_blocks=blocks, channels=ch) as pe:
+        pe.load_resnet(blob)
+        cb = co.make_predict_cb(lambda bs: pe.predict(np.stack(bs)), (6, 7), 7)
+        ref = co.generate("connect4", sims, n, seed=seed, predict_cb=cb, trace=False)
+
+    class Net:
+        def state_dict(self):
+            return {k: v for k, v in sd.items() if "num_batches_tracked" not in k}
+
+    np.random.seed(seed)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    eps = list(gen.generate_episodes(Net()))
+    assert float(np.random.random_sample()) == ref["next_uniform"]
+    for e, ep in enumerate(eps):
+        lo, hi = ref["ep_offset"][e], ref["ep_offset"][e + 1]
+        assert np.array_equal(np.stack([s.state for s in ep.samples]).reshape(hi - lo, -1), ref["states"][lo:hi])
+        assert np.array_equal(np.stack([s.policy for s in ep.samples]), ref["policies"][lo:hi])
+        assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()
+
+
+def test_resnet_model_predict_uses_device_kernel(azsp):
+    import torch
+    torch.manual_seed(0)
+    net = azsp.ResNet((6, 7), 7, 2, 32)
+    net.eval()
+    rules = oz.C4Rules()
+    boards = random_midgame_boards(rules, np.random.RandomState(2), 20, 30)
+    p, v = net.predict(boards)
+    with torch.no_grad():
+        logits, vl = net.forward(net._states_to_tensor(boards))
+        mask = torch.tensor([rules.valid_moves(b) for b in boards])
+        pt = torch.softmax(logits.masked_fill(mask == 0, float("-inf")), dim=1).numpy()
+        vt = torch.tanh(vl).numpy()
+    assert np.max(np.abs(np.stack(p) - pt)) < 1e-5 and np.max(np.abs(np.array(v) - vt)) < 1e-5
+    clone = net.get_inference_clone()
+    assert clone._azsp_engine is None and net._azsp_engine is not None
+
+
+# ------------------------------------------------------------------------------------ full size
+def test_full_size_config2_properties(azsp):
+    """BASELINE.json configs[1]: Connect-4, 64-ch/4-block ResNet, 100 sims, 4096 concurrent games.
+    Too large for the oracle; checked through size-independent invariants of every episode."""
+    import torch
+    torch.manual_seed(0)
+    net = azsp.ResNet((6, 7), 7, 4, 64)
+    n, sims = 4096, 100
+    np.random.seed(0)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    eps = list(gen.generate_episodes(net))
+    assert len(eps) == n
+    rules = oz.C4Rules()
+    for ep in eps[::7]:
+        check_episode_invariants(rules, np.stack([s.state for s in ep.samples]),
+                                 np.stack([s.policy for s in ep.samples]), [s.value for s in ep.samples], sims)
+    st = gen.last_stats
+    assert st["rounds"] == st["plies"] * (sims + 1)
+    assert st["evals"] + st["terminal_leaves"] == st["plies"] * n * (sims + 1)
+
+
+def test_error_paths(azsp):
+    from azsp._lib import AzspError
+    with pytest.raises(AzspError):
+        _engine(azsp, "connect4", 0, 10)
+    with _engine(azsp, "connect4", 4, 5) as e:
+        with pytest.raises(AzspError):
+            e.play(np.zeros(4))                 # play before search
+        with pytest.raises(AzspError):
+            e.load_resnet(np.zeros(10, np.float32))
+        with pytest.raises(ValueError):
+            e.search() or e.play(np.zeros(3))
+        boom = RuntimeError("predict failed")
+
+        def bad(_):
+            raise boom
+        e.use_host_evaluator(bad)
+        with pytest.raises(RuntimeError, match="predict failed"):
+            e.search()
+    with pytest.raises(NotImplementedError):
+        class Other:
+            pass
+        _engine(azsp, Other(), 4, 5)

@@ -1,0 +1,104 @@
+"""CPU tests of the host-side mirror: game plugins vs the reference fixtures, weight export,
+episode JSON schema, and that the C-ABI library loads and exports every declared symbol."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import load_json
+
+import azsp
+from azsp import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("fname,game", [("rules_connect4.json", azsp.Connect4Game()),
+                                        ("rules_connect2.json", azsp.Connect2Game())])
+def test_host_games_match_reference(fname, game):
+    for c in load_json(fname)["cases"]:
+        b = np.array(c["board"], dtype=int)
+        nb, npl = game.get_next_state(b, c["player"], c["action"])
+        assert nb.tolist() == c["next"] and npl == c["next_player"]
+        assert game.get_valid_moves(b) == c["valid"]
+        assert game.has_legal_moves(b) == c["has_moves"]
+        assert game.is_win(b, 1) == c["win_p"] and game.is_win(b, -1) == c["win_m"]
+        assert game.get_reward_for_player(b, 1) == c["reward_p"]
+        assert game.get_reward_for_player(b, -1) == c["reward_m"]
+    assert game.get_action_size() == len(c["valid"])
+    assert np.all(game.get_init_board() == 0)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "azsp.h")).read()
+    declared = set(re.findall(r"\b(azsp_[a-z_0-9]+)\s*\(", header))
+    declared -= {"azsp_predict_fn"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.azsp_abi_version() == 1
+    import ctypes as C
+    r, c, a, mp = (C.c_int32() for _ in range(4))
+    assert lib.azsp_game_info(0, C.byref(r), C.byref(c), C.byref(a), C.byref(mp)) == 0
+    assert (r.value, c.value, a.value, mp.value) == (6, 7, 7, 42)
+    assert lib.azsp_game_info(7, None, None, None, None) != 0
+    assert b"unknown game" in lib.azsp_last_error()
+    assert lib.azsp_record_bytes(0) == 48 + 56
+
+
+def test_weight_blob_layout():
+    import torch
+    from azsp.weights import resnet_blob, resnet_key_order
+    torch.manual_seed(1)
+    net = azsp.ResNet((6, 7), 7, 3, 32)
+    blob, blocks, ch = resnet_blob(net)
+    assert (blocks, ch) == (3, 32)
+    assert blob.dtype == np.float32 and blob.size == _lib.load().azsp_resnet_blob_floats(0, 3, 32)
+    sd = net.state_dict()
+    off = 0
+    for k in resnet_key_order(3):
+        t = sd[k].numpy().reshape(-1)
+        assert np.array_equal(blob[off:off + t.size], t)
+        off += t.size
+    assert off == blob.size
+    # same state_dict keys as the reference fixture (checkpoint interchange)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "resnet_forward.npz"))
+    ref_keys = {k[5:] for k in z.files if k.startswith("m_sd/")}
+    assert ref_keys == set(azsp.ResNet((6, 7), 7, 4, 64).state_dict().keys())
+
+
+def test_resnet_forward_matches_reference_vectors_on_cpu_torch():
+    """The host ResNet (training path, PyTorch) reproduces the reference's logits from its weights."""
+    import torch
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "resnet_forward.npz"))
+    for tag in ("s", "m"):
+        blocks, ch = z[f"{tag}_arch"].tolist()
+        net = azsp.ResNet((6, 7), 7, blocks, ch)
+        net.load_state_dict({k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{tag}_sd/")})
+        net.eval()
+        with torch.no_grad():
+            logits, vl = net.forward(net._states_to_tensor(list(z["boards"].astype(np.int64))))
+        assert np.max(np.abs(logits.numpy() - z[f"{tag}_logits"])) < 1e-5
+        assert np.max(np.abs(vl.numpy() - z[f"{tag}_vlogit"])) < 1e-5
+
+
+def test_episode_json_schema_roundtrip():
+    ep = azsp.Episode()
+    ep.add_sample(azsp.Sample(state=np.zeros((6, 7), dtype=np.int64), policy=np.full(7, 1 / 7), value=1))
+    d = ep.to_dict()
+    assert set(d) == {"samples"} and set(d["samples"][0]) == {"state", "policy", "value"}
+    back = azsp.Episode.from_dict(d)
+    assert len(back) == 1 and back.samples[0].value == 1 and np.array_equal(back.current_state, ep.current_state)
+
+
+def test_format_dataset_accepts_generator_output():
+    import torch
+    net = azsp.ResNet((6, 7), 7, 1, 32)
+    states = [np.zeros((6, 7), dtype=np.int64), -np.eye(6, 7, dtype=np.int64)]
+    ds = net.format_dataset(states, [np.full(7, 1 / 7)] * 2, [1, -1])
+    x, pi, z = ds.tensors
+    assert x.shape == (2, 3, 6, 7) and pi.dtype == torch.float32 and z.tolist() == [1.0, -1.0]
+    loss = net.training_step((x, pi, z), 0)
+    assert torch.isfinite(loss)
