@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void k_resnet_forward(NetParams P, const u64 *
     constexpr int ZERO_IDX = WG_ROWS * STRIDE;
     extern __shared__ float smem[];
     float *act = smem;                             // [WG_ROWS + 1][STRIDE]
-    float *part = smem + (WG_ROWS + 1) * STRIDE;   // [WG_ROWS][8] FC partial sums, then logits
+    float *part = smem + (WG_ROWS + 1) * STRIDE;   // [WG_ROWS][8] FC partial sums, then [TB][8] logits
+    float *hval = part + WG_ROWS * 8 + TB * 8;     // [WG_ROWS][4] value-head activations
 
     const int n_leaf = *n_leaf_p;
     const int board0 = blockIdx.x * TB;
@@ -245,14 +246,14 @@ __global__ __launch_bounds__(256) void k_resnet_forward(NetParams P, const u64 *
     conv_mfma<G, MT, 1, 1, S>(accp, P.pol_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
     conv_mfma<G, MT, 1, 9, S>(accv, P.val_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
     __syncthreads();
-    // head activations over the (now dead) tower activations: cols [0,32) policy, [32,35) value
+    // policy-head activations over the (now dead) tower activations, value-head ones beside them
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int row = wave * 64 + mt * 32 + cd_row(v, lane);
             act[row * STRIDE + (lane & 31)] = fmaxf(accp[mt][0][v], 0.0f);
-            if ((lane & 31) < VAL_CH) act[row * STRIDE + POL_CH + (lane & 31)] = fmaxf(accv[mt][0][v], 0.0f);
+            if ((lane & 31) < VAL_CH) hval[row * 4 + (lane & 31)] = fmaxf(accv[mt][0][v], 0.0f);
         }
     __syncthreads();
 
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void k_resnet_forward(NetParams P, const u64 *
         }
         float pv = 0.0f;
 #pragma unroll
-        for (int c = 0; c < VAL_CH; ++c) pv = fmaf(hrow[POL_CH + c], P.fcv_w[c * CELLS + pos], pv);
+        for (int c = 0; c < VAL_CH; ++c) pv = fmaf(hval[tid * 4 + c], P.fcv_w[c * CELLS + pos], pv);
         pa[7] = pv;
 #pragma unroll
         for (int o = 0; o < 8; ++o) part[tid * 8 + o] = pa[o];
@@ -466,7 +467,7 @@ static void launch_forward(const ResNetDev *n, const NetParams &P, const u64 *mi
                            const int32_t *n_leaf, int max_leaves, float *out_p, float *out_v, hipStream_t s) {
     constexpr int TB = WG_ROWS / G::CELLS;
     constexpr int STRIDE = 32 * NT + 1;
-    const size_t lds = ((size_t)(WG_ROWS + 1) * STRIDE + WG_ROWS * 8 + TB * 8 + 8) * sizeof(float);
+    const size_t lds = ((size_t)(WG_ROWS + 1) * STRIDE + WG_ROWS * 8 + TB * 8 + WG_ROWS * 4) * sizeof(float);
     static bool attr_set[64] = {};
     int dev = 0;
     hipGetDevice(&dev);

@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Self-play throughput benchmark (BASELINE.json: "self-play episodes/sec (Connect-4, 100 sims/move)").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one complete `EpisodeGenerator.generate_episodes` call of the workload: `--slots`
+concurrent Connect-4 games per GPU (default 4096 = BASELINE.json configs[1]), `--sims` MCTS
+simulations per move, random-weight ResNet(`--blocks`, `--channels`), run until `slots` episodes have
+completed (reference stop rule), examples copied to the host, and -- for N > 1 -- the packed
+(s, pi, z) records all-gathered over RCCL.  Games shard over GPUs with no other traffic (weak scaling).
+
+The JSON line carries the MFMA roofline of the dominant kernel (k_resnet_forward, timed with HIP
+events on the engine's own stream inside the timed region) and a CPU baseline: the oracle's
+pure-Python/torch-CPU port of the reference path timed on this box's host cores (rank 0, N=1 only)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "alphazero-implementation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def resnet_flops_per_board(blocks: int, ch: int, cells: int = 42, actions: int = 7) -> float:
+    """2*MAC over conv + linear layers of resnet.py:44-72 (25 254 012 for 4 blocks x 64 ch)."""
+    conv = cells * (3 * 9 * ch + 2 * blocks * ch * ch * 9 + ch * 32 + ch * 9 * 3)
+    fc = 32 * cells * actions + 3 * cells
+    return 2.0 * (conv + fc)
+
+
+def cpu_baseline(blocks: int, ch: int, sims: int, slots: int, state_dict) -> dict:
+    """oracle/az_oracle.py + oracle/resnet_ref.py (port of the reference's Python/torch-CPU path)."""
+    from oracle import az_oracle as oz
+    from oracle.resnet_ref import ResNetRef
+    cores = os.cpu_count() or 1
+    threads = min(cores, 16)
+    torch.set_num_threads(threads)
+    net = ResNetRef(state_dict)
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    eps = list(oz.generate_episodes(oz.C4Rules(), net.predict, sims, slots))
+    dt = time.perf_counter() - t0
+    return {"value": len(eps) / dt, "unit": "episodes/s", "cores": threads, "kind": "port",
+            "sample": f"{slots} concurrent games x {sims} sims, first {len(eps)} completions, {dt:.1f} s, "
+                      f"{net.boards_seen} net evals, host has {cores} logical cores"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--slots", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=100)
+    ap.add_argument("--blocks", type=int, default=4)
+    ap.add_argument("--channels", type=int, default=64)
+    ap.add_argument("--cpu-slots", type=int, default=16, help="concurrent games of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the self-play engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import azsp
+    from azsp.distributed import all_gather_records
+
+    torch.manual_seed(0)                       # same random-weight net on every rank
+    net = azsp.ResNet((6, 7), 7, args.blocks, args.channels)
+    net.eval()
+    cfg = azsp.AlphaZeroConfig(batch_size=32, num_iterations=1, num_simulations=args.sims, num_episodes=args.slots,
+                               num_iters_for_train_history=1, epochs=1)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg, device=local_rank, timing=True)
+
+    def step(seed: int):
+        np.random.seed(seed)                   # independent replica per rank (SURVEY 8e mode B)
+        eps = list(gen.generate_episodes(net))
+        n_samples = sum(len(e) for e in eps)
+        gathered = all_gather_records(gen, dist, world) if world > 1 else None
+        return len(eps), n_samples, gathered
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(1000 * (w + 1) + rank)
+    eng = gen.engine_for(net)
+    eng.reset_stats()
+    fence()
+    t0 = time.perf_counter()
+    episodes = samples = 0
+    for k in range(args.steps):
+        e, s, _ = step(10 * k + rank)
+        episodes += e
+        samples += s
+    fence()
+    dt = time.perf_counter() - t0
+    st = eng.stats()
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([episodes, samples], device="cuda", dtype=torch.int64)
+        dist.all_reduce(tot)
+        episodes, samples = int(tot[0]), int(tot[1])
+
+    if rank == 0:
+        fpb = resnet_flops_per_board(args.blocks, args.channels)
+        launches = max(int(st["infer_launches"]), 1)
+        avg_ms = st["infer_ms"] / launches
+        boards_per_launch = st["infer_boards"] / launches
+        achieved = fpb * boards_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "self-play episodes/sec (Connect-4, 100 sims/move)" if args.sims == 100 else
+                      f"self-play episodes/sec (Connect-4, {args.sims} sims/move)",
+            "value": episodes / dt, "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (empty-board starts, random-weight net, seeded RNG)",
+            "config": {"workload": f"Connect-4 self-play, ResNet {args.channels}ch/{args.blocks}blk random weights, "
+                                   f"{args.sims} sims/move, {args.slots} concurrent games per GPU, first "
+                                   f"{args.slots} completions per GPU per step",
+                       "slots_per_gpu": args.slots, "sims": args.sims, "parallelism": f"game-sharded x{world}",
+                       "episodes": episodes, "samples": samples,
+                       "mean_plies_per_episode": samples / max(episodes, 1)},
+            "roofline": {"bound": "mfma", "kernel": "k_resnet_forward", "achieved": achieved,
+                         "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
+                         "traffic": None, "flops_per_board": fpb, "boards_per_launch": boards_per_launch,
+                         "avg_launch_ms": avg_ms, "launches": launches,
+                         "infer_share_of_wall": st["infer_ms"] * 1e-3 / dt if dt > 0 else None},
+            "tree": {"select_ms": st["select_ms"], "expand_ms": st["expand_ms"], "play_ms": st["play_ms"],
+                     "rounds": int(st["rounds"]), "evals": int(st["evals"]),
+                     "terminal_leaves": int(st["terminal_leaves"]), "path_nodes": int(st["path_nodes"])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.blocks, args.channels, args.sims, args.cpu_slots, net.state_dict())
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

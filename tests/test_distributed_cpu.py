@@ -1,0 +1,65 @@
+"""world_size-2 gloo test of the N>1 path: variable-length all-gather of packed (s, pi, z) records,
+plus pack/unpack round trip of the device record layout."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from azsp.distributed import all_gather_variable, pack_records, record_bytes, unpack_records
+
+
+def _records(rank: int, n: int):
+    rng = np.random.RandomState(100 + rank)
+    states = rng.randint(-1, 2, size=(n, 42)).astype(np.int8)
+    counts = rng.randint(0, 30, size=(n, 7))
+    counts[:, 0] += 1
+    policies = counts / counts.sum(axis=1, keepdims=True)
+    values = rng.randint(-1, 2, size=n).astype(np.int32)
+    return states, policies, values
+
+
+def _worker(rank: int, world: int, port: int, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = [5, 13][rank]
+        local = torch.from_numpy(pack_records(*_records(rank, n)))
+        parts = all_gather_variable(local, dist, world)
+        ok = len(parts) == world
+        for r, part in enumerate(parts):
+            s, p, v = unpack_records(part.numpy(), 42, 7)
+            es, ep, ev = _records(r, [5, 13][r])
+            ok = ok and np.array_equal(s, es) and np.array_equal(p, ep) and np.array_equal(v, ev)
+        empty = all_gather_variable(local[:0] if rank == 0 else local, dist, world)     # a rank with nothing
+        ok = ok and empty[0].shape[0] == 0 and empty[1].shape[0] == 13
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pack_unpack_roundtrip():
+    s, p, v = _records(0, 17)
+    rec = pack_records(s, p, v)
+    assert rec.shape == (17, record_bytes(42, 7)) == (17, 104)
+    s2, p2, v2 = unpack_records(rec, 42, 7)
+    assert np.array_equal(s, s2) and np.array_equal(p, p2) and np.array_equal(v, v2)
+
+
+def test_all_gather_variable_gloo_world2():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results == {0: True, 1: True}

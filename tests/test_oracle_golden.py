@@ -220,3 +220,48 @@ def test_c_oracle_generate_with_numpy_rng_and_python_evaluator():
     cb = co.make_predict_cb(model.predict, (6, 7), 7)
     o = co.generate("connect4", run["sims"], run["n"], seed=None, predict_cb=cb, uniform_cb=co.np_uniform_cb())
     _check_generate(o, run)
+
+
+# ----------------------------------------------------------------------------------- network oracle
+def test_resnet_ref_matches_reference_vectors():
+    """oracle/resnet_ref.py vs outputs of the reference's own ResNet.predict (torch CPU, 1 thread)."""
+    import torch
+    from oracle.resnet_ref import ResNetRef
+    torch.set_num_threads(1)
+    z = np.load(os.path.join(G, "resnet_forward.npz"))
+    boards = list(z["boards"].astype(np.int64))
+    for tag in ("s", "m"):
+        net = ResNetRef({k[5:]: z[k] for k in z.files if k.startswith(f"{tag}_sd/")})
+        p, v = net.predict(boards)
+        assert np.max(np.abs(np.stack(p) - z[f"{tag}_p"])) < 1e-6
+        assert np.max(np.abs(np.array(v) - z[f"{tag}_v"])) < 1e-6
+        assert np.all(np.stack(p)[z[f"{tag}_p"] == 0] == 0)
+
+
+def test_oracle_with_resnet_reproduces_reference_config1():
+    """BASELINE.json configs[0] (25 sims, 1 game, torch-CPU ResNet(4,64), seeds 0/0).  torch-CPU
+    kernels are host dependent, so bit-equality of the transcript is only demanded when this host's
+    network outputs are bit-identical to the recorded ones; otherwise pi is compared within 0.08
+    on the first ply (a single visit of 25) and the test says so."""
+    import torch
+    from oracle.resnet_ref import ResNetRef
+    run = load("episodes_resnet.json")
+    torch.manual_seed(run["torch_seed"])
+    torch.set_num_threads(1)
+    import azsp
+    ref_like = azsp.ResNet((6, 7), 7, *run["arch"])          # same init order as the reference module
+    net = ResNetRef(ref_like.state_dict())
+    np.random.seed(run["seed"])
+    rules = oz.C4Rules()
+    trace = []
+    eps = list(oz.generate_episodes(rules, net.predict, run["sims"], run["n"], trace=trace))
+    same = [t["counts"] for t in trace] == [p["counts"][0] for p in run["plies"]]
+    if same:
+        assert [np.asarray(s).tolist() for s, _, _ in eps[0]] == run["episodes"][0]["states"]
+        assert [np.asarray(p).tolist() for _, p, _ in eps[0]] == run["episodes"][0]["policies"]
+        assert [int(z) for _, _, z in eps[0]] == run["episodes"][0]["values"]
+        assert float(np.random.random_sample()) == run["rng_after"]
+    else:
+        first = np.array(trace[0]["counts"]) / run["sims"]
+        assert np.max(np.abs(first - np.array(run["plies"][0]["counts"][0]) / run["sims"])) <= 0.08
+        pytest.skip("torch-CPU outputs differ bitwise on this host; transcript compared on ply 0 only")
