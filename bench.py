@@ -65,7 +65,7 @@ def main() -> None:
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--blocks", type=int, default=4)
     ap.add_argument("--channels", type=int, default=64)
-    ap.add_argument("--cpu-slots", type=int, default=16, help="concurrent games of the CPU baseline sample")
+    ap.add_argument("--cpu-slots", type=int, default=48, help="concurrent games of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
