@@ -19,7 +19,7 @@ ABI_VERSION = 1
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("game", C.c_int32), ("n_slots", C.c_int32), ("n_sims", C.c_int32),
                 ("device", C.c_int32), ("res_blocks", C.c_int32), ("channels", C.c_int32), ("flags", C.c_uint32),
-                ("hash_salt", C.c_uint64)]
+                ("hash_salt", C.c_uint64), ("n_groups", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PlyResult(C.Structure):
@@ -32,7 +32,7 @@ class Stats(C.Structure):
                 ("terminal_leaves", C.c_uint64), ("infer_launches", C.c_uint64), ("infer_ms", C.c_double),
                 ("infer_boards", C.c_uint64), ("select_ms", C.c_double), ("expand_ms", C.c_double),
                 ("play_ms", C.c_double), ("select_launches", C.c_uint64), ("expand_launches", C.c_uint64),
-                ("path_nodes", C.c_uint64)]
+                ("path_nodes", C.c_uint64), ("infer_union_ms", C.c_double)]
 
 
 PREDICT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int8), C.c_int32, C.POINTER(C.c_float),

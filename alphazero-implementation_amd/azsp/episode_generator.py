@@ -19,11 +19,13 @@ from .mcts import configure_engine_for_model, default_device, engine_geometry_fo
 
 
 class EpisodeGenerator:
-    def __init__(self, *, game, config: AlphaZeroConfig, device: int | None = None, timing: bool = False):
+    def __init__(self, *, game, config: AlphaZeroConfig, device: int | None = None, timing: bool = False,
+                 n_groups: int = 0):
         self.game = game
         self.config = config
         self.device = device
         self.timing = timing
+        self.n_groups = n_groups      # concurrent slot groups (HIP streams); 0 = automatic; never changes results
         self._engine: Engine | None = None
         self._engine_key = None
         self.last_stats: dict | None = None
@@ -36,7 +38,8 @@ class EpisodeGenerator:
                 self._engine.close()
             dev = default_device() if self.device is None else self.device
             self._engine = Engine(self.game, self.config.num_episodes, self.config.num_simulations, device=dev,
-                                  res_blocks=blocks, channels=ch, timing=self.timing, hash_salt=salt)
+                                  res_blocks=blocks, channels=ch, timing=self.timing, hash_salt=salt,
+                                  n_groups=self.n_groups)
             self._engine_key = key
         configure_engine_for_model(self._engine, model)
         return self._engine
@@ -47,8 +50,8 @@ class EpisodeGenerator:
         shape = eng.board_shape
         eng.reset()
         emitted = 0
+        eng.search()
         while True:
-            eng.search()
             rng_state = np.random.get_state()
             res = eng.play(np.random.random_sample(n))
             if res.uniforms_used < n:
@@ -56,6 +59,9 @@ class EpisodeGenerator:
                 # of that ply never draw.  Rewind so the global RNG ends where the reference leaves it.
                 np.random.set_state(rng_state)
                 np.random.random_sample(res.uniforms_used)
+            if not res.finished:
+                eng.search()        # enqueue the next ply's search now: it runs on the GPU while the
+                                    # host copies and materialises the episodes that just finished
             if res.n_finished:
                 out = eng.fetch_episodes(emitted, res.n_finished)
                 states = out["states"].astype(np.int64).reshape((-1,) + shape)

@@ -6,7 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/azsp.h"
@@ -54,7 +56,10 @@ struct EventPair { hipEvent_t a, b; int kind; };
 struct azsp_engine {
     azsp_config cfg{};
     GameInfo gi{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                 // main stream (group 0 runs on it too)
+    hipStream_t gstream[MAX_GROUPS] = {};         // gstream[0] == stream
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
+    int n_groups = 1;
     View v{};
     std::vector<void *> allocs;
     int evaluator = AZSP_EVAL_HASH;
@@ -81,6 +86,8 @@ struct azsp_engine {
     size_t ev_used = 0;
     azsp_stats stats{};
     uint64_t plies = 0;
+    uint64_t rounds_host = 0;
+    double infer_union_ms = 0;
 };
 
 template <class T>
@@ -95,7 +102,7 @@ static int dev_alloc(azsp_engine *e, T *&p, size_t n) {
 #define DEV_ALLOC(ptr, n) do { int _rc = dev_alloc(e, ptr, (size_t)(n)); if (_rc) return _rc; } while (0)
 
 // ---- timing -------------------------------------------------------------------------------------
-static EventPair *ev_begin(azsp_engine *e, int kind) {
+static EventPair *ev_begin(azsp_engine *e, int kind, hipStream_t st) {
     if (!(e->cfg.flags & AZSP_FLAG_TIMING)) return nullptr;
     if (e->ev_used == e->ev_pool.size()) {
         EventPair p{};
@@ -104,21 +111,43 @@ static EventPair *ev_begin(azsp_engine *e, int kind) {
     }
     EventPair *p = &e->ev_pool[e->ev_used++];
     p->kind = kind;
-    hipEventRecord(p->a, e->stream);
+    (void)hipEventRecord(p->a, st);
     return p;
 }
-static void ev_end(azsp_engine *e, EventPair *p) { if (p) hipEventRecord(p->b, e->stream); }
+static void ev_end(EventPair *p, hipStream_t st) { if (p) (void)hipEventRecord(p->b, st); }
 
-static void ev_collect(azsp_engine *e) {       // call only after a stream synchronize
+static void ev_collect(azsp_engine *e) {       // call only after the streams have been synchronised
+    // Inference launches of different slot groups overlap in time; besides the per-launch sum, keep
+    // the length of the union of their [start, end] intervals (same device => one time base).
+    std::vector<std::pair<float, float>> iv;
+    hipEvent_t base = nullptr;
     for (size_t i = 0; i < e->ev_used; ++i) {
+        const EventPair &p = e->ev_pool[i];
         float ms = 0;
-        if (hipEventElapsedTime(&ms, e->ev_pool[i].a, e->ev_pool[i].b) != hipSuccess) continue;
-        switch (e->ev_pool[i].kind) {
-            case EV_INFER: e->stats.infer_ms += ms; break;
+        if (hipEventElapsedTime(&ms, p.a, p.b) != hipSuccess) continue;
+        switch (p.kind) {
+            case EV_INFER: {
+                e->stats.infer_ms += ms;
+                if (!base) base = p.a;
+                float t0 = 0;
+                if (base != p.a && hipEventElapsedTime(&t0, base, p.a) != hipSuccess) break;
+                iv.emplace_back(t0, t0 + ms);
+                break;
+            }
             case EV_SELECT: e->stats.select_ms += ms; break;
             case EV_EXPAND: e->stats.expand_ms += ms; break;
             case EV_PLAY: e->stats.play_ms += ms; break;
         }
+    }
+    if (!iv.empty()) {
+        std::sort(iv.begin(), iv.end());
+        float lo = iv[0].first, hi = iv[0].second;
+        double tot = 0;
+        for (size_t i = 1; i < iv.size(); ++i) {
+            if (iv[i].first > hi) { tot += hi - lo; lo = iv[i].first; hi = iv[i].second; }
+            else if (iv[i].second > hi) hi = iv[i].second;
+        }
+        e->infer_union_ms += tot + (hi - lo);
     }
     e->ev_used = 0;
 }
@@ -129,68 +158,99 @@ static int sync_stream(azsp_engine *e) {
     return 0;
 }
 
-// ---- evaluation of the compacted leaves ------------------------------------------------------------
-static int evaluate_leaves(azsp_engine *e, int max_leaves) {
+// ---- evaluation of the compacted leaves of one slot group ------------------------------------------
+static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
     const int game = e->cfg.game;
     switch (e->evaluator) {
         case AZSP_EVAL_HASH:
-            launch_eval_hash(game, e->v, e->cfg.hash_salt, e->stream);
+            launch_eval_hash(game, v, e->cfg.hash_salt, st);
             return 0;
         case AZSP_EVAL_RESNET: {
             if (!e->net || !e->net_loaded) return fail(AZSP_ERR_STATE, "ResNet evaluator selected but no weights loaded (azsp_load_resnet)");
-            EventPair *p = ev_begin(e, EV_INFER);
-            resnet_forward(e->net, game, e->v.leaf_mine, e->v.leaf_theirs, e->v.leaf_slot, e->v.n_leaf, max_leaves,
-                           e->v.eval_p, e->v.eval_v, e->stream);
-            ev_end(e, p);
+            EventPair *p = ev_begin(e, EV_INFER, st);
+            resnet_forward(e->net, game, v.leaf_mine, v.leaf_theirs, v.leaf_slot + v.lo, v.n_leaf + v.grp, v.n_act,
+                           v.eval_p + (size_t)v.lo * PSTRIDE, v.eval_v + v.lo, st);
+            ev_end(p, st);
             e->stats.infer_launches++;
             return 0;
         }
         case AZSP_EVAL_HOST: {
             if (!e->cb) return fail(AZSP_ERR_STATE, "host evaluator selected but no callback set");
+            if (v.lo != 0) return fail(AZSP_ERR_STATE, "host evaluator needs a single slot group");
             const int A = e->gi.A, cells = e->gi.cells;
-            launch_leaf_cells(game, e->v, e->d_cells, e->stream);
-            HIP_TRY(hipMemcpyAsync(e->h_nleaf, e->v.n_leaf, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-            HIP_TRY(hipStreamSynchronize(e->stream));
+            launch_leaf_cells(game, v, e->d_cells, st);
+            HIP_TRY(hipMemcpyAsync(e->h_nleaf, v.n_leaf, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
             const int m = *e->h_nleaf;
             if (m <= 0) return 0;
-            HIP_TRY(hipMemcpyAsync(e->h_cells.data(), e->d_cells, (size_t)m * cells, hipMemcpyDeviceToHost, e->stream));
-            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(hipMemcpyAsync(e->h_cells.data(), e->d_cells, (size_t)m * cells, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
             if (e->cb(e->cb_user, e->h_cells.data(), m, e->h_p.data(), e->h_v.data()))
                 return fail(AZSP_ERR_CALLBACK, "host evaluator callback reported failure");
             for (int j = 0; j < m; ++j)
                 for (int a = 0; a < PSTRIDE; ++a) e->h_p8[(size_t)j * PSTRIDE + a] = a < A ? e->h_p[(size_t)j * A + a] : 0.0f;
-            HIP_TRY(hipMemcpyAsync(e->v.eval_p, e->h_p8.data(), (size_t)m * PSTRIDE * sizeof(float), hipMemcpyHostToDevice, e->stream));
-            HIP_TRY(hipMemcpyAsync(e->v.eval_v, e->h_v.data(), (size_t)m * sizeof(float), hipMemcpyHostToDevice, e->stream));
-            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(hipMemcpyAsync(v.eval_p, e->h_p8.data(), (size_t)m * PSTRIDE * sizeof(float), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(v.eval_v, e->h_v.data(), (size_t)m * sizeof(float), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
             return 0;
         }
     }
     return fail(AZSP_ERR_ARG, "unknown evaluator kind %d", e->evaluator);
 }
 
-// MCTS.run_batch on the first n_act slots (monte_carlo_tree_search.py:111-171)
+// MCTS.run_batch on the first n_act slots (monte_carlo_tree_search.py:111-171).
+// Games are independent, so the slots are cut into contiguous groups and each group's dependent
+// chain select -> compact -> evaluate -> expand is enqueued on its own HIP stream: the tail of one
+// group's inference launch overlaps the next group's, and the latency-bound tree kernels of one
+// group hide behind the other's MFMA work.  Results do not depend on the grouping.
 static int search(azsp_engine *e, int n_act) {
     const int game = e->cfg.game;
-    e->v.n_act = n_act;
-    launch_root_prepare(game, e->v, e->stream);
-    launch_compact(e->v, e->stream);
-    int rc = evaluate_leaves(e, n_act);
-    if (rc) return rc;
-    launch_expand(game, e->v, e->stream);
-    for (int s = 0; s < e->cfg.n_sims; ++s) {
-        EventPair *p = ev_begin(e, EV_SELECT);
-        launch_select(game, e->v, e->stream);
-        launch_compact(e->v, e->stream);
-        ev_end(e, p);
-        e->stats.select_launches++;
-        rc = evaluate_leaves(e, n_act);
-        if (rc) return rc;
-        p = ev_begin(e, EV_EXPAND);
-        launch_expand(game, e->v, e->stream);
-        ev_end(e, p);
-        e->stats.expand_launches++;
+    int G = e->n_groups;
+    if (e->evaluator == AZSP_EVAL_HOST || n_act < 64 * G) G = 1;
+    View gv[MAX_GROUPS];
+    for (int k = 0; k < G; ++k) {
+        gv[k] = e->v;
+        gv[k].grp = k;
+        gv[k].lo = (int)((long long)n_act * k / G);
+        gv[k].n_act = (int)((long long)n_act * (k + 1) / G) - gv[k].lo;
     }
+    if (G > 1) {
+        HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
+        for (int k = 1; k < G; ++k) HIP_TRY(hipStreamWaitEvent(e->gstream[k], e->ev_fork, 0));
+    }
+    for (int k = 0; k < G; ++k) {
+        hipStream_t st = e->gstream[k];
+        launch_root_prepare(game, gv[k], st);
+        launch_compact(gv[k], st);
+        int rc = evaluate_leaves(e, gv[k], st);
+        if (rc) return rc;
+        launch_expand(game, gv[k], st);
+    }
+    for (int s = 0; s < e->cfg.n_sims; ++s) {
+        for (int k = 0; k < G; ++k) {
+            hipStream_t st = e->gstream[k];
+            EventPair *p = ev_begin(e, EV_SELECT, st);
+            launch_select(game, gv[k], st);
+            launch_compact(gv[k], st);
+            ev_end(p, st);
+            e->stats.select_launches++;
+            int rc = evaluate_leaves(e, gv[k], st);
+            if (rc) return rc;
+            p = ev_begin(e, EV_EXPAND, st);
+            launch_expand(game, gv[k], st);
+            ev_end(p, st);
+            e->stats.expand_launches++;
+        }
+    }
+    for (int k = 1; k < G; ++k) {
+        HIP_TRY(hipEventRecord(e->ev_join[k], e->gstream[k]));
+        HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join[k], 0));
+    }
+    e->v.lo = 0;
+    e->v.grp = 0;
+    e->v.n_act = n_act;
     e->stats.plies++;
+    e->rounds_host += (uint64_t)e->cfg.n_sims + 1;
     e->searched = true;
     return 0;
 }
@@ -227,8 +287,13 @@ size_t azsp_resnet_blob_floats(int32_t game, int32_t res_blocks, int32_t channel
 void azsp_destroy(azsp_engine *e) {
     if (!e) return;
     hipSetDevice(e->cfg.device);
-    if (e->stream) hipStreamSynchronize(e->stream);
-    for (auto &p : e->ev_pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (int k = 0; k < MAX_GROUPS; ++k) if (e->gstream[k]) (void)hipStreamSynchronize(e->gstream[k]);
+    for (auto &p : e->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (int k = 1; k < MAX_GROUPS; ++k) {
+        if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
+        if (e->gstream[k]) (void)hipStreamDestroy(e->gstream[k]);
+    }
     if (e->net) resnet_destroy(e->net);
     for (void *p : e->allocs) hipFree(p);
     if (e->h_res) hipHostFree(e->h_res);
@@ -243,9 +308,18 @@ static int create_impl(azsp_engine *e) {
     const GameInfo &gi = e->gi;
     HIP_TRY(hipSetDevice(c.device));
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->gstream[0] = e->stream;
+    e->n_groups = c.n_groups > 0 ? (c.n_groups > MAX_GROUPS ? MAX_GROUPS : c.n_groups) : (c.n_slots >= 2048 ? 2 : 1);
+    for (int k = 1; k < e->n_groups; ++k) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->gstream[k], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     View &v = e->v;
     const int N = c.n_slots, A = gi.A, S = c.n_sims;
     v.n_slots = v.n_act = N;
+    v.lo = 0;
+    v.grp = 0;
     v.A = A;
     v.n_sims = S;
     v.E = S + 1;
@@ -259,7 +333,9 @@ static int create_impl(azsp_engine *e) {
     DEV_ALLOC(v.n_blk, N);
     DEV_ALLOC(v.path, (size_t)N * v.D); DEV_ALLOC(v.path_len, N); DEV_ALLOC(v.leaf_node, N);
     DEV_ALLOC(v.leaf_mine, N); DEV_ALLOC(v.leaf_theirs, N); DEV_ALLOC(v.pending, N);
-    DEV_ALLOC(v.leaf_slot, N); DEV_ALLOC(v.n_leaf, 4);
+    DEV_ALLOC(v.leaf_slot, N); DEV_ALLOC(v.n_leaf, MAX_GROUPS);
+    HIP_TRY(hipMemset(v.leaf_slot, 0, (size_t)N * sizeof(int32_t)));
+    HIP_TRY(hipMemset(v.n_leaf, 0, MAX_GROUPS * sizeof(int32_t)));
     DEV_ALLOC(v.eval_p, (size_t)N * PSTRIDE); DEV_ALLOC(v.eval_v, N);
     double *sq = nullptr;
     DEV_ALLOC(sq, S + 2);
@@ -371,9 +447,11 @@ int azsp_predict(azsp_engine *e, const int8_t *boards, int32_t n, float *p_out, 
         int rc = upload_boards(e, boards + (size_t)lo * e->gi.cells, m);
         if (rc) return rc;
         e->v.n_act = m;
+        e->v.lo = 0;
+        e->v.grp = 0;
         launch_root_prepare(e->cfg.game, e->v, e->stream);
         launch_compact(e->v, e->stream);
-        rc = evaluate_leaves(e, m);
+        rc = evaluate_leaves(e, e->v, e->stream);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(e->h_p8.data(), e->v.eval_p, (size_t)m * PSTRIDE * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipMemcpyAsync(e->h_v.data(), e->v.eval_v, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, e->stream));
@@ -446,10 +524,10 @@ int azsp_play(azsp_engine *e, const double *uniforms, azsp_ply_result *out) {
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int N = e->cfg.n_slots;
     HIP_TRY(hipMemcpyAsync(e->d_uniforms, uniforms, (size_t)N * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    EventPair *p = ev_begin(e, EV_PLAY);
+    EventPair *p = ev_begin(e, EV_PLAY, e->stream);
     launch_finish(e->cfg.game, e->v, e->d_uniforms, e->stream);
     launch_emit(e->cfg.game, e->v, e->h_res, e->stream);
-    ev_end(e, p);
+    ev_end(p, e->stream);
     int rc = sync_stream(e);
     if (rc) return rc;
     out->ply = e->h_res->ply;
@@ -466,7 +544,8 @@ int azsp_fetch_episodes(azsp_engine *e, int64_t first, int64_t n, int64_t *ep_of
                         int8_t *states, double *policies, int32_t *values, int64_t sample_cap) {
     if (!e || first < 0 || n < 0) return fail(AZSP_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    // No stream synchronisation: emitted episodes were complete when azsp_play returned, and the arena
+    // is append-only until the next azsp_play, so a search already enqueued may run during the copy.
     if (first + n > e->h_res->episodes_total) return fail(AZSP_ERR_ARG, "episodes [%lld,%lld) not emitted yet (have %lld)", (long long)first, (long long)(first + n), (long long)e->h_res->episodes_total);
     if (n == 0) return 0;
     std::vector<int64_t> off((size_t)n + 1);
@@ -509,7 +588,8 @@ int azsp_get_stats(azsp_engine *e, azsp_stats *out) {
     e->stats.evals = e->h_counters[0];
     e->stats.terminal_leaves = e->h_counters[1];
     e->stats.path_nodes = e->h_counters[2];
-    e->stats.rounds = e->h_counters[3];
+    e->stats.rounds = e->rounds_host;
+    e->stats.infer_union_ms = e->infer_union_ms;
     e->stats.infer_boards = e->evaluator == AZSP_EVAL_RESNET ? e->h_counters[0] : 0;
     *out = e->stats;
     return 0;
@@ -522,6 +602,8 @@ int azsp_reset_stats(azsp_engine *e) {
     if (rc) return rc;
     HIP_TRY(hipMemset(e->v.counters, 0, 8 * sizeof(unsigned long long)));
     e->stats = azsp_stats{};
+    e->rounds_host = 0;
+    e->infer_union_ms = 0;
     return 0;
 }
 

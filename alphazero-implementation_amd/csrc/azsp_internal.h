@@ -9,6 +9,7 @@ namespace azsp {
 
 constexpr int LANES = 8;     // lanes per game in the tree kernels (one per action, A <= 8)
 constexpr int PSTRIDE = 8;   // floats per policy row in the evaluation buffers
+constexpr int MAX_GROUPS = 8; // slot groups searched concurrently on separate HIP streams
 
 // Device-resident state of one engine.  Structure-of-arrays; every per-node array is [slot][C].
 //
@@ -18,7 +19,9 @@ constexpr int PSTRIDE = 8;   // floats per policy row in the evaluation buffers
 //   kids[x]           first child of x (1 + e*A), 0 while x is unexpanded
 //   blk_parent[e]     the node whose children are block e;  st_*[e] = its canonical position
 struct View {
-    int32_t n_act;     // active slots (n_slots, or fewer for azsp_run_batch)
+    int32_t lo;        // first slot of the group this launch works on (groups run on separate streams)
+    int32_t grp;       // group index: selects n_leaf[grp]
+    int32_t n_act;     // slots in the group: [lo, lo + n_act)
     int32_t n_slots;
     int32_t A;         // actions
     int32_t C;         // node capacity per tree (array stride)
@@ -42,9 +45,9 @@ struct View {
     int32_t *leaf_node;     // [n_slots]
     u64     *leaf_mine, *leaf_theirs;   // [n_slots] canonical position at the leaf
     uint8_t *pending;       // [n_slots] leaf awaits evaluation
-    int32_t *leaf_slot;     // [n_slots] compacted (slot order) list of pending slots
-    int32_t *n_leaf;        // [1]
-    float   *eval_p;        // [n_slots][PSTRIDE] evaluator output, indexed by compacted leaf
+    int32_t *leaf_slot;     // [n_slots] per group, at offset lo: compacted (slot order) list of pending slots
+    int32_t *n_leaf;        // [MAX_GROUPS]
+    float   *eval_p;        // [n_slots][PSTRIDE] evaluator output, at offset lo, indexed by compacted leaf
     float   *eval_v;        // [n_slots]
     const double *sqrt_tab; // [n_sims + 2] host-computed sqrt(i): bit-identical to math.sqrt
     // live games

@@ -36,6 +36,7 @@ __device__ __forceinline__ int shfl8_i(int x, int src) { return __shfl(x, src, L
 __global__ void k_root_prepare(View v) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= v.n_act) return;
+    g += v.lo;
     size_t base = (size_t)g * v.C;
     v.cnt[base] = 0;
     v.wsum[base] = 0.0f;
@@ -59,9 +60,10 @@ __global__ __launch_bounds__(64) void k_select(View v) {
     extern __shared__ int s_path[];                 // [8 games][D]
     const int lane = threadIdx.x & (LANES - 1);
     const int grp = threadIdx.x >> 3;
-    const int g = blockIdx.x * (64 / LANES) + grp;
-    const bool live = g < v.n_act;
-    const size_t base = (size_t)(live ? g : 0) * v.C;
+    const int gl = blockIdx.x * (64 / LANES) + grp;
+    const bool live = gl < v.n_act;
+    const int g = live ? v.lo + gl : 0;
+    const size_t base = (size_t)g * v.C;
     int *my_path = s_path + grp * v.D;
 
     int node = 0, depth = 0, parent_fc = 0, action = 0;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(1024) void k_compact(View v) {
     __shared__ int s_sum[1024];
     const int t = threadIdx.x;
     const int per = (v.n_act + 1023) / 1024;
-    const int lo = t * per, hi = min(lo + per, v.n_act);
+    const int lo = v.lo + t * per, hi = min(lo + per, v.lo + v.n_act);
     int c = 0;
     for (int g = lo; g < hi; ++g) c += v.pending[g];
     s_sum[t] = c;
@@ -165,13 +167,12 @@ __global__ __launch_bounds__(1024) void k_compact(View v) {
         s_sum[t] += x;
         __syncthreads();
     }
-    int pos = s_sum[t] - c;
+    int pos = v.lo + s_sum[t] - c;
     for (int g = lo; g < hi; ++g)
         if (v.pending[g]) v.leaf_slot[pos++] = g;
     if (t == 1023) {
-        v.n_leaf[0] = s_sum[1023];
+        v.n_leaf[v.grp] = s_sum[1023];
         atomicAdd(&v.counters[0], (unsigned long long)s_sum[1023]);
-        atomicAdd(&v.counters[3], 1ull);
     }
 }
 
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(1024) void k_compact(View v) {
 template <class G>
 __global__ void k_eval_hash(View v, uint64_t salt) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= v.n_leaf[0]) return;
+    if (j >= v.n_leaf[v.grp]) return;
+    j += v.lo;
     const int g = v.leaf_slot[j];
     const u64 m = v.leaf_mine[g], t = v.leaf_theirs[g];
     float p[G::A];
@@ -198,9 +200,10 @@ template <class G>
 __global__ __launch_bounds__(64) void k_expand(View v) {
     constexpr int A = G::A;
     const int lane = threadIdx.x & (LANES - 1);
-    const int j = (blockIdx.x * 64 + threadIdx.x) >> 3;
-    const bool live = j < v.n_leaf[0];
-    const int g = live ? v.leaf_slot[j] : 0;
+    const int jl = (blockIdx.x * 64 + threadIdx.x) >> 3;
+    const bool live = jl < v.n_leaf[v.grp];
+    const int j = v.lo + (live ? jl : 0);
+    const int g = v.leaf_slot[j];
     const size_t base = (size_t)g * v.C;
     const u64 mine = v.leaf_mine[g], theirs = v.leaf_theirs[g];
     const uint32_t legal = G::legal_mask(mine, theirs);
@@ -246,8 +249,8 @@ __global__ __launch_bounds__(64) void k_expand(View v) {
 template <class G>
 __global__ void k_leaf_cells(View v, int8_t *dst) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= v.n_leaf[0]) return;
-    const int g = v.leaf_slot[j];
+    if (j >= v.n_leaf[v.grp]) return;
+    const int g = v.leaf_slot[v.lo + j];
     bits_to_cells<G>(v.leaf_mine[g], v.leaf_theirs[g], dst + (size_t)j * G::CELLS);
 }
 

@@ -56,6 +56,9 @@ typedef struct azsp_config {
     int32_t  channels;       /* ResNet num_channels  (resnet.py:36)                                   */
     uint32_t flags;          /* AZSP_FLAG_*                                                           */
     uint64_t hash_salt;      /* AZSP_EVAL_HASH only                                                   */
+    int32_t  n_groups;       /* slot groups searched concurrently on separate HIP streams (1..8);
+                                0 = automatic.  Results do not depend on it.                          */
+    int32_t  reserved;
 } azsp_config;
 
 /* Host evaluator: boards int8[n][cells] (canonical) -> p float32[n][n_actions], v float32[n].
@@ -84,6 +87,8 @@ typedef struct azsp_stats {
     double   select_ms, expand_ms, play_ms;   /* tree kernels, HIP-event sums                        */
     uint64_t select_launches, expand_launches;
     uint64_t path_nodes;               /* sum of backup path lengths (for algorithmic bytes)         */
+    double   infer_union_ms;           /* time during which >= 1 inference launch was running (launches
+                                          of different slot groups overlap)                            */
 } azsp_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

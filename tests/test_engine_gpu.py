@@ -120,12 +120,14 @@ def test_per_ply_root_counts_match_reference_fixtures(azsp):
         assert res.finished and res.episodes_total == run["n"]
 
 
-@pytest.mark.parametrize("n,sims,seed,salt", [(512, 100, 11, 3), (64, 400, 12, 8), (1, 100, 13, 0), (3, 1, 14, 1)])
-def test_generate_matches_c_oracle_at_larger_sizes(azsp, n, sims, seed, salt):
+@pytest.mark.parametrize("n,sims,seed,salt,groups", [(512, 100, 11, 3, 1), (512, 100, 11, 3, 4), (2048, 30, 15, 2, 0),
+                                                     (64, 400, 12, 8, 0), (1, 100, 13, 0, 0), (3, 1, 14, 1, 0)])
+def test_generate_matches_c_oracle_at_larger_sizes(azsp, n, sims, seed, salt, groups):
+    """Also covers the multi-stream slot groups: results must not depend on the grouping."""
     ref = co.generate("connect4", sims, n, salt, seed=seed, trace=False)
     cfg = azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1)
     np.random.seed(seed)
-    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg, n_groups=groups)
     eps = list(gen.generate_episodes(HashStub("connect4", salt)))
     assert float(np.random.random_sample()) == ref["next_uniform"]
     assert len(eps) == n
