@@ -19,6 +19,7 @@
 //     order, then masked softmax / tanh.  Every board's result is independent of which tile /
 //     row it landed in (batch-invariant), so leaf order does not influence the search.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -29,7 +30,6 @@ namespace azsp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int WG_ROWS = 256;
 constexpr int POL_CH = 32;      // policy head conv channels (resnet.py:57)
 constexpr int VAL_CH = 3;       // value head conv channels  (resnet.py:66)
 constexpr float BN_EPS = 1e-5f;
@@ -106,13 +106,15 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
 //   row = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5),  col = l & 31
 __device__ __forceinline__ int cd_row(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
 
-template <class G, int NT>
-__global__ __launch_bounds__(256) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
+template <class G, int NT, int MT>
+__global__ __launch_bounds__(256, (MT == 1 ? 3 : (NT <= 2 ? 2 : 1))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
                                                          const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
                                                          float *__restrict__ out_p, float *__restrict__ out_v) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
+    constexpr int WG_ROWS = 128 * MT;              // 4 waves x MT row tiles of 32
+    constexpr int WROWS = 32 * MT;                 // rows per wave
     constexpr int TB = WG_ROWS / CELLS;            // boards per workgroup
-    constexpr int CP = 32 * NT, S = CP / 2, STRIDE = CP + 1, MT = 2;
+    constexpr int CP = 32 * NT, S = CP / 2, STRIDE = CP + 1;
     constexpr int ZERO_IDX = WG_ROWS * STRIDE;
     extern __shared__ float smem[];
     float *act = smem;                             // [WG_ROWS + 1][STRIDE]
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void k_resnet_forward(NetParams P, const u64 *
     int ry[MT], rx[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int r = wave * 64 + mt * 32 + (lane & 31);
+        const int r = wave * WROWS + mt * 32 + (lane & 31);
         const int b = r / CELLS, pos = r % CELLS;
         const int y = pos / COLS, x = pos % COLS;
         const bool real = r < TB * CELLS && board0 + b < n_leaf;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void k_resnet_forward(NetParams P, const u64 *
                 for (int v = 0; v < 16; ++v) {
                     const float o = fmaxf(acc[mt][nt][v], 0.0f);
                     xres[mt][nt][v] = o;
-                    act[(wave * 64 + mt * 32 + cd_row(v, lane)) * STRIDE + nt * 32 + (lane & 31)] = o;
+                    act[(wave * WROWS + mt * 32 + cd_row(v, lane)) * STRIDE + nt * 32 + (lane & 31)] = o;
                 }
     }
     __syncthreads();
@@ -229,32 +231,58 @@ __global__ __launch_bounds__(256) void k_resnet_forward(NetParams P, const u64 *
                 for (int v = 0; v < 16; ++v) {
                     const float o = fmaxf(acc[mt][nt][v], 0.0f);
                     if (second) xres[mt][nt][v] = o;
-                    act[(wave * 64 + mt * 32 + cd_row(v, lane)) * STRIDE + nt * 32 + (lane & 31)] = o;
+                    act[(wave * WROWS + mt * 32 + cd_row(v, lane)) * STRIDE + nt * 32 + (lane & 31)] = o;
                 }
         __syncthreads();
     }
 
     // ---- heads: policy conv1x1(C->32)+BN+ReLU (resnet.py:56-59), value conv3x3(C->3)+BN+ReLU (:65-68)
-    f32x16 accp[MT][1], accv[MT][1];
+    f32x16 accp[MT][1];
     {
-        const float bp = P.pol_b[lane & 31], bv = P.val_b[lane & 31];
+        const float bp = P.pol_b[lane & 31];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) { accp[mt][0][v] = bp; accv[mt][0][v] = bv; }
+            for (int v = 0; v < 16; ++v) accp[mt][0][v] = bp;
     }
     conv_mfma<G, MT, 1, 1, S>(accp, P.pol_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
-    conv_mfma<G, MT, 1, 9, S>(accv, P.val_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
+    // The value conv has 3 output channels: on the matrix pipe it would be padded to a 32-wide tile
+    // (+5.8 % MFMA time for 0.6 % of the FLOPs), so it runs on the vector ALU instead -- one thread per
+    // board cell, weights wave-uniform (scalar loads), activations read conflict-free from LDS --
+    // where it overlaps with the other resident workgroups' MFMA phases.
+    float hv0 = 0.0f, hv1 = 0.0f, hv2 = 0.0f;
+    if (tid < TB * CELLS) {
+        const int pos = tid % CELLS, y = pos / COLS, x = pos % COLS;
+        const bool real = board0 + tid / CELLS < n_leaf;
+        hv0 = P.val_b[0]; hv1 = P.val_b[1]; hv2 = P.val_b[2];
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            const bool ok = real && yy >= 0 && yy < ROWS && xx >= 0 && xx < COLS;
+            const float *xr = act + (ok ? (tid + (t / 3 - 1) * COLS + (t % 3 - 1)) * STRIDE : ZERO_IDX);
+            const float *wv = P.val_w + (size_t)t * CP * 4;
+#pragma unroll 8
+            for (int c = 0; c < CP; ++c) {
+                const float a = xr[c];
+                hv0 = fmaf(a, wv[c * 4 + 0], hv0);
+                hv1 = fmaf(a, wv[c * 4 + 1], hv1);
+                hv2 = fmaf(a, wv[c * 4 + 2], hv2);
+            }
+        }
+    }
     __syncthreads();
     // policy-head activations over the (now dead) tower activations, value-head ones beside them
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int row = wave * 64 + mt * 32 + cd_row(v, lane);
+            const int row = wave * WROWS + mt * 32 + cd_row(v, lane);
             act[row * STRIDE + (lane & 31)] = fmaxf(accp[mt][0][v], 0.0f);
-            if ((lane & 31) < VAL_CH) hval[row * 4 + (lane & 31)] = fmaxf(accv[mt][0][v], 0.0f);
         }
+    if (tid < TB * CELLS) {
+        hval[tid * 4 + 0] = fmaxf(hv0, 0.0f);
+        hval[tid * 4 + 1] = fmaxf(hv1, 0.0f);
+        hval[tid * 4 + 2] = fmaxf(hv2, 0.0f);
+    }
     __syncthreads();
 
     // ---- Linear layers: Flatten is (c, y, x) order (resnet.py:60-61, :69-70) -------------------------
@@ -319,7 +347,7 @@ static bool geom_for(int game, int blocks, int channels, NetGeom &g) {
     if (g.NT != 1 && g.NT != 2 && g.NT != 4) return false;      // 32/64/128 channels after padding
     g.S = g.Cp / 2;
     g.blocks = blocks;
-    g.TB = WG_ROWS / g.cells;
+    g.TB = 256 / g.cells;
     return true;
 }
 
@@ -387,7 +415,7 @@ ResNetDev *resnet_create(int game, int blocks, int channels) {
     n->o_conv_b = reserve(n->conv_b_stride * 2 * blocks);
     n->o_pol_w = reserve((size_t)g.S * 64);
     n->o_pol_b = reserve(32);
-    n->o_val_w = reserve((size_t)9 * g.S * 64);
+    n->o_val_w = reserve((size_t)9 * g.Cp * 4);
     n->o_val_b = reserve(32);
     n->o_fcp_w = reserve((size_t)POL_CH * g.cells * 8);
     n->o_fcp_b = reserve(8);
@@ -450,7 +478,10 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
     {
         ConvBN c = take_conv_bn(p, VAL_CH, g.C, 3);
         fold(c, w, b);
-        permute_conv(w, VAL_CH, g.C, 3, g.S, 1, host.data() + n->o_val_w);
+        for (int tap = 0; tap < 9; ++tap)           // vector-ALU layout: [tap][channel][4]
+            for (int c2 = 0; c2 < g.C; ++c2)
+                for (int o = 0; o < VAL_CH; ++o)
+                    host[n->o_val_w + ((size_t)tap * g.Cp + c2) * 4 + o] = w[((size_t)o * g.C + c2) * 9 + tap];
         for (int o = 0; o < VAL_CH; ++o) host[n->o_val_b + o] = b[o];
         const float *fw = take(p, (size_t)VAL_CH * g.cells), *fb = take(p, 1);
         for (int i = 0; i < VAL_CH * g.cells; ++i) host[n->o_fcv_w + i] = fw[i];
@@ -462,22 +493,23 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
     return 0;
 }
 
-template <class G, int NT>
-static void launch_forward(const ResNetDev *n, const NetParams &P, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot,
+template <class G, int NT, int MT>
+static void launch_forward(const NetParams &P, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot,
                            const int32_t *n_leaf, int max_leaves, float *out_p, float *out_v, hipStream_t s) {
+    constexpr int WG_ROWS = 128 * MT;
     constexpr int TB = WG_ROWS / G::CELLS;
     constexpr int STRIDE = 32 * NT + 1;
     const size_t lds = ((size_t)(WG_ROWS + 1) * STRIDE + WG_ROWS * 8 + TB * 8 + WG_ROWS * 4) * sizeof(float);
     static bool attr_set[64] = {};
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT, MT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev] = true;
     }
     const int grid = (max_leaves + TB - 1) / TB;
-    hipLaunchKernelGGL((k_resnet_forward<G, NT>), dim3(grid), dim3(256), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
-    (void)n;
+    hipLaunchKernelGGL((k_resnet_forward<G, NT, MT>), dim3(grid), dim3(256), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
 }
 
 void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
@@ -493,9 +525,14 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
     P.conv_w_stride = (int)n->conv_w_stride;
     P.conv_b_stride = (int)n->conv_b_stride;
     P.blocks = n->g.blocks;
-#define FWD(GT, NTV) launch_forward<GT, NTV>(n, P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
     (void)game;
-    if (n->g.NT == 1) FWD(Connect4, 1); else if (n->g.NT == 2) FWD(Connect4, 2); else FWD(Connect4, 4);
+    // rows per workgroup: 2 row tiles per wave (6 boards / WG) by default; AZSP_RESNET_MT=1 selects
+    // 1 row tile per wave (3 boards / WG, more workgroups per CU) -- same results, tuning knob only
+    static const int mt = [] { const char *e = getenv("AZSP_RESNET_MT"); return e && e[0] == '1' ? 1 : 2; }();
+#define FWD(NTV, MTV) launch_forward<Connect4, NTV, MTV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
+    if (n->g.NT == 1) { if (mt == 1) FWD(1, 1); else FWD(1, 2); }
+    else if (n->g.NT == 2) { if (mt == 1) FWD(2, 1); else FWD(2, 2); }
+    else FWD(4, 2);
 #undef FWD
 }
 
