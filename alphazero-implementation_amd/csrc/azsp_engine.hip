@@ -309,7 +309,7 @@ static int create_impl(azsp_engine *e) {
     HIP_TRY(hipSetDevice(c.device));
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->gstream[0] = e->stream;
-    e->n_groups = c.n_groups > 0 ? (c.n_groups > MAX_GROUPS ? MAX_GROUPS : c.n_groups) : (c.n_slots >= 2048 ? 2 : 1);
+    e->n_groups = c.n_groups > 0 ? (c.n_groups > MAX_GROUPS ? MAX_GROUPS : c.n_groups) : (c.n_slots >= 3072 ? 3 : (c.n_slots >= 1024 ? 2 : 1));
     for (int k = 1; k < e->n_groups; ++k) {
         HIP_TRY(hipStreamCreateWithFlags(&e->gstream[k], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
