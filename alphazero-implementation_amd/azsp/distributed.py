@@ -68,5 +68,10 @@ def export_records(gen, device: torch.device | None = None) -> torch.Tensor:
     return buf[:n]
 
 
-def all_gather_records(gen, dist, world: int) -> list[torch.Tensor]:
-    return all_gather_variable(export_records(gen), dist, world)
+def all_gather_records(gen, dist, world: int, coll_device: torch.device | None = None) -> list[torch.Tensor]:
+    """Every rank ends up with every rank's records.  `coll_device` = where the collective runs
+    (the GPU for RCCL; CPU for the gloo rehearsal mode)."""
+    rec = export_records(gen)
+    if coll_device is not None and coll_device.type != rec.device.type:
+        rec = rec.to(coll_device)
+    return all_gather_variable(rec, dist, world)

@@ -77,12 +77,19 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the self-play engine has no CPU path")
+    # one process per GPU; AZSP_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks
+    backend = os.environ.get("AZSP_BENCH_BACKEND", "nccl")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=coll_dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import azsp
     from azsp.distributed import all_gather_records
@@ -99,7 +106,7 @@ def main() -> None:
         np.random.seed(seed)                   # independent replica per rank (SURVEY 8e mode B)
         eps = list(gen.generate_episodes(net))
         n_samples = sum(len(e) for e in eps)
-        gathered = all_gather_records(gen, dist, world) if world > 1 else None
+        gathered = all_gather_records(gen, dist, world, coll_dev) if world > 1 else None
         return len(eps), n_samples, gathered
 
     def fence():
@@ -113,21 +120,25 @@ def main() -> None:
     eng.reset_stats()
     fence()
     t0 = time.perf_counter()
-    episodes = samples = 0
+    episodes = samples = gathered_records = 0
     for k in range(args.steps):
-        e, s, _ = step(10 * k + rank)
+        e, s, g = step(10 * k + rank)
         episodes += e
         samples += s
+        if g is not None:
+            gathered_records += sum(int(x.shape[0]) for x in g)
     fence()
     dt = time.perf_counter() - t0
     st = eng.stats()
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([episodes, samples], device="cuda", dtype=torch.int64)
+        tot = torch.tensor([episodes, samples], device=coll_dev, dtype=torch.int64)
         dist.all_reduce(tot)
         episodes, samples = int(tot[0]), int(tot[1])
+        if gathered_records != samples:
+            raise SystemExit(f"rank {rank}: all-gather delivered {gathered_records} records, expected {samples}")
 
     if rank == 0:
         fpb = resnet_flops_per_board(args.blocks, args.channels)

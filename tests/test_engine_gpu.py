@@ -257,3 +257,23 @@ def test_error_paths(azsp):
         class Other:
             pass
         _engine(azsp, Other(), 4, 5)
+
+
+def test_device_record_export_matches_host_fetch(azsp):
+    """azsp_export_records_device (the payload of the multi-GPU all-gather) == the episodes fetched to
+    the host, record for record."""
+    import torch
+    from azsp.distributed import export_records, unpack_records
+    n, sims = 256, 20
+    np.random.seed(3)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    eps = list(gen.generate_episodes(HashStub("connect4", 4)))
+    rec = export_records(gen).cpu().numpy()
+    s, p, v = unpack_records(rec, 42, 7)
+    assert rec.shape == (sum(len(e) for e in eps), 104)
+    k = 0
+    for ep in eps:
+        for smp in ep.samples:
+            assert np.array_equal(s[k].reshape(6, 7), smp.state) and np.array_equal(p[k], smp.policy) and v[k] == smp.value
+            k += 1
+    assert torch.cuda.is_available()
