@@ -67,7 +67,7 @@ def engine_geometry_for_model(model) -> tuple[int, int, int]:
     sd = model.state_dict() if hasattr(model, "state_dict") else None
     if sd is not None and is_resnet_state_dict(sd):
         _, blocks, ch = resnet_blob(sd)
-        if (ch + 31) // 32 in (1, 2, 4):
+        if 1 <= (ch + 31) // 32 <= 4:
             return blocks, ch, 0
     return 0, 0, 0
 

@@ -63,6 +63,7 @@ template <int NT>
 __device__ __forceinline__ void load_w(const float *p, float (&w)[NT]) {
     if constexpr (NT == 1) { w[0] = p[0]; }
     else if constexpr (NT == 2) { float2 t = *reinterpret_cast<const float2 *>(p); w[0] = t.x; w[1] = t.y; }
+    else if constexpr (NT == 3) { w[0] = p[0]; w[1] = p[1]; w[2] = p[2]; }
     else {
 #pragma unroll
         for (int i = 0; i < NT; i += 4) { float4 t = *reinterpret_cast<const float4 *>(p + i); w[i] = t.x; w[i + 1] = t.y; w[i + 2] = t.z; w[i + 3] = t.w; }
@@ -74,10 +75,68 @@ __device__ __forceinline__ void load_w(const float *p, float (&w)[NT]) {
 //   wl   : permuted weights [tap][S][64][NTW]
 //   ridx : per row tile, float index of this lane's row (+ lane>>5) in `act`
 //   vmask: per row tile, 9-bit tap validity
-template <class G, int MT, int NTW, int TAPS, int S>
+template <int NTW, int KB>
+__device__ __forceinline__ void load_wblock(const float *p, float (&w)[KB][NTW]) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) load_w<NTW>(p + (size_t)i * 64 * NTW, w[i]);
+}
+
+template <int MT, int NTW, int KB>
+__device__ __forceinline__ void mfma_block(f32x16 (&acc)[MT][NTW], const float *const (&arow)[MT], int s0,
+                                           const float (&w)[KB][NTW]) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+        float a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = arow[mt][2 * (s0 + i)];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], w[i][nt], acc[mt][nt], 0, 0, 0);
+    }
+}
+
+template <class G, int MT, int NTW, int TAPS, int S, int PF>
 __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *__restrict__ wl, const float *act,
                                           const int (&ridx)[MT], const uint32_t (&vmask)[MT], int stride, int zero_idx,
                                           int lane) {
+    if constexpr (PF == 0) {
+        // compiler-scheduled form: one load + MT LDS reads + MT*NTW MFMAs per k-step, fully unrolled per tap
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int t9 = (TAPS == 9) ? tap : 4;
+            const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+            const float *arow[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                arow[mt] = act + (((vmask[mt] >> t9) & 1u) ? ridx[mt] + (dy * G::COLS + dx) * stride : zero_idx);
+            const float *wt = wl + ((size_t)tap * S * 64 + lane) * NTW;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                float w[NTW];
+                load_w<NTW>(wt + (size_t)s * 64 * NTW, w);
+                float a[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = arow[mt][2 * s];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], w[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        return;
+    }
+    // Weights stream through two register blocks of KB k-steps each: while the MFMAs of one block
+    // issue (KB * MT * NTW * 64 cycles), the loads of the next block (possibly the next tap's first)
+    // are in flight, so L2 latency never reaches the matrix pipe.  The buffer past the last block
+    // of the layer is prefetched too (the blob is padded accordingly) and simply not used.
+    constexpr int KB = 8, NB = S / KB;
+    static_assert(S % (2 * KB) == 0, "k-steps per tap must be a multiple of 16");
+    const float *wp = wl + (size_t)lane * NTW;
+    constexpr size_t BLK = (size_t)KB * 64 * NTW;
+    float wA[KB][NTW], wB[KB][NTW];
+    load_wblock<NTW, KB>(wp, wA);
     for (int tap = 0; tap < TAPS; ++tap) {
         const int t9 = (TAPS == 9) ? tap : 4;
         const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
@@ -85,19 +144,13 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             arow[mt] = act + (((vmask[mt] >> t9) & 1u) ? ridx[mt] + (dy * G::COLS + dx) * stride : zero_idx);
-        const float *wt = wl + ((size_t)tap * S * 64 + lane) * NTW;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            float w[NTW];
-            load_w<NTW>(wt + (size_t)s * 64 * NTW, w);
-            float a[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = arow[mt][2 * s];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], w[nt], acc[mt][nt], 0, 0, 0);
+        for (int b = 0; b < NB; b += 2) {
+            load_wblock<NTW, KB>(wp + BLK, wB);
+            mfma_block<MT, NTW, KB>(acc, arow, b * KB, wA);
+            load_wblock<NTW, KB>(wp + 2 * BLK, wA);
+            mfma_block<MT, NTW, KB>(acc, arow, (b + 1) * KB, wB);
+            wp += 2 * BLK;
         }
     }
 }
@@ -106,8 +159,8 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
 //   row = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5),  col = l & 31
 __device__ __forceinline__ int cd_row(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
 
-template <class G, int NT, int MT>
-__global__ __launch_bounds__(256, (MT == 1 ? 3 : (NT <= 2 ? 2 : 1))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
+template <class G, int NT, int MT, int PF>
+__global__ __launch_bounds__(256, (MT == 1 && NT <= 2 ? 3 : 2)) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
                                                          const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
                                                          float *__restrict__ out_p, float *__restrict__ out_v) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
@@ -221,7 +274,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : (NT <= 2 ? 2 : 1))) void k_resn
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[mt][nt][v] = second ? xres[mt][nt][v] + bias : bias;   // x += residual
         }
-        conv_mfma<G, MT, NT, 9, S>(acc, wl, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
+        conv_mfma<G, MT, NT, 9, S, PF>(acc, wl, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
         __syncthreads();                               // every wave is done reading the layer input
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -245,7 +298,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : (NT <= 2 ? 2 : 1))) void k_resn
 #pragma unroll
             for (int v = 0; v < 16; ++v) accp[mt][0][v] = bp;
     }
-    conv_mfma<G, MT, 1, 1, S>(accp, P.pol_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
+    conv_mfma<G, MT, 1, 1, S, PF>(accp, P.pol_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
     // The value conv has 3 output channels: on the matrix pipe it would be padded to a 32-wide tile
     // (+5.8 % MFMA time for 0.6 % of the FLOPs), so it runs on the vector ALU instead -- one thread per
     // board cell, weights wave-uniform (scalar loads), activations read conflict-free from LDS --
@@ -344,7 +397,7 @@ static bool geom_for(int game, int blocks, int channels, NetGeom &g) {
     g.C = channels;
     g.Cp = (channels + 31) / 32 * 32;
     g.NT = g.Cp / 32;
-    if (g.NT != 1 && g.NT != 2 && g.NT != 4) return false;      // 32/64/128 channels after padding
+    if (g.NT < 1 || g.NT > 4) return false;      // up to 128 channels (after padding to a multiple of 32)
     g.S = g.Cp / 2;
     g.blocks = blocks;
     g.TB = 256 / g.cells;
@@ -421,6 +474,7 @@ ResNetDev *resnet_create(int game, int blocks, int channels) {
     n->o_fcp_b = reserve(8);
     n->o_fcv_w = reserve((size_t)VAL_CH * g.cells);
     n->o_fcv_b = reserve(4);
+    off += 8 * 64 * 4;                      // slack for the one-block weight prefetch past the last array
     n->blob_floats = off;
     if (hipMalloc((void **)&n->d_blob, off * sizeof(float)) != hipSuccess) { delete n; return nullptr; }
     const double C = g.C, cells = g.cells;
@@ -493,7 +547,7 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
     return 0;
 }
 
-template <class G, int NT, int MT>
+template <class G, int NT, int MT, int PF>
 static void launch_forward(const NetParams &P, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot,
                            const int32_t *n_leaf, int max_leaves, float *out_p, float *out_v, hipStream_t s) {
     constexpr int WG_ROWS = 128 * MT;
@@ -504,12 +558,12 @@ static void launch_forward(const NetParams &P, const u64 *mine, const u64 *their
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT, MT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT, MT, PF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev] = true;
     }
     const int grid = (max_leaves + TB - 1) / TB;
-    hipLaunchKernelGGL((k_resnet_forward<G, NT, MT>), dim3(grid), dim3(256), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
+    hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF>), dim3(grid), dim3(256), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
 }
 
 void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
@@ -529,10 +583,17 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
     // rows per workgroup: 2 row tiles per wave (6 boards / WG) by default; AZSP_RESNET_MT=1 selects
     // 1 row tile per wave (3 boards / WG, more workgroups per CU) -- same results, tuning knob only
     static const int mt = [] { const char *e = getenv("AZSP_RESNET_MT"); return e && e[0] == '1' ? 1 : 2; }();
-#define FWD(NTV, MTV) launch_forward<Connect4, NTV, MTV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
-    if (n->g.NT == 1) { if (mt == 1) FWD(1, 1); else FWD(1, 2); }
-    else if (n->g.NT == 2) { if (mt == 1) FWD(2, 1); else FWD(2, 2); }
-    else FWD(4, 2);
+    static const int pf = [] { const char *e = getenv("AZSP_RESNET_PF"); return e ? atoi(e) : -1; }();
+#define FWD(NTV, MTV, PFV) launch_forward<Connect4, NTV, MTV, PFV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
+    // PF: explicit register double-buffering of the weight stream (helps the wide nets at MT=1; the
+    // 64-channel MT=2 kernel is faster with the compiler's own schedule) -- measured, see DESIGN.md
+    if (n->g.NT == 1) { if (mt == 1) FWD(1, 1, 0); else FWD(1, 2, 0); }
+    else if (n->g.NT == 2) {
+        if (mt == 1) { if (pf == 1) FWD(2, 1, 1); else FWD(2, 1, 0); }
+        else { if (pf == 1) FWD(2, 2, 1); else FWD(2, 2, 0); }
+    }
+    else if (n->g.NT == 3) { if (pf == 0) FWD(3, 1, 0); else FWD(3, 1, 1); }
+    else { if (pf == 0) FWD(4, 1, 0); else FWD(4, 1, 1); }
 #undef FWD
 }
 

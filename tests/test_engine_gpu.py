@@ -196,13 +196,23 @@ def test_resnet_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp):
         assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()
 
 
-def test_resnet_model_predict_uses_device_kernel(azsp):
+@pytest.mark.parametrize("blocks,ch", [(2, 32), (1, 16), (3, 48), (2, 128), (8, 128), (1, 100)])
+def test_resnet_model_predict_uses_device_kernel(azsp, blocks, ch):
+    """azsp.ResNet.predict (HIP kernel) vs the same module's PyTorch forward on the CPU, for every
+    channel-tile count the kernel is instantiated for (C padded to 32/64/128).  Tolerance 1e-5."""
     import torch
-    torch.manual_seed(0)
-    net = azsp.ResNet((6, 7), 7, 2, 32)
+    torch.manual_seed(blocks * 1000 + ch)
+    net = azsp.ResNet((6, 7), 7, blocks, ch)
+    with torch.no_grad():                          # non-trivial BatchNorm statistics
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
     net.eval()
     rules = oz.C4Rules()
-    boards = random_midgame_boards(rules, np.random.RandomState(2), 20, 30)
+    boards = random_midgame_boards(rules, np.random.RandomState(2), 20, 40)
     p, v = net.predict(boards)
     with torch.no_grad():
         logits, vl = net.forward(net._states_to_tensor(boards))
@@ -212,6 +222,10 @@ def test_resnet_model_predict_uses_device_kernel(azsp):
     assert np.max(np.abs(np.stack(p) - pt)) < 1e-5 and np.max(np.abs(np.array(v) - vt)) < 1e-5
     clone = net.get_inference_clone()
     assert clone._azsp_engine is None and net._azsp_engine is not None
+    with torch.no_grad():                          # weights change -> next predict re-uploads
+        net.policy_head[4].bias[0] += 1.0         # (a uniform shift would leave the softmax unchanged)
+    p2, _ = net.predict(boards)
+    assert not np.allclose(np.stack(p2), np.stack(p))
 
 
 # ------------------------------------------------------------------------------------ full size
