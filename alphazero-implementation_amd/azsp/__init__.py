@@ -5,7 +5,8 @@ from .episode import Episode, Sample
 from .games import BaseGame, Connect2Game, Connect4Game
 
 __all__ = ["AlphaZeroConfig", "Episode", "Sample", "BaseGame", "Connect2Game", "Connect4Game",
-           "BaseModel", "ResNet", "MCTS", "Node", "EpisodeGenerator", "Engine"]
+           "BaseModel", "ResNet", "MCTS", "Node", "EpisodeGenerator", "Engine", "generate_dataset",
+           "DeviceReplayBuffer", "save_episodes", "load_episodes"]
 
 
 def __getattr__(name):          # torch / libazsp are only imported when their classes are used
@@ -21,4 +22,7 @@ def __getattr__(name):          # torch / libazsp are only imported when their c
     if name == "Engine":
         from .engine import Engine
         return Engine
+    if name in ("generate_dataset", "DeviceReplayBuffer", "save_episodes", "load_episodes"):
+        from . import replay
+        return getattr(replay, name)
     raise AttributeError(name)

@@ -162,6 +162,14 @@ class Engine:
             L.check(int(got))
         return int(got)
 
+    def export_dataset_device(self, first: int, n: int, planes_ptr: int, policies_ptr: int, values_ptr: int,
+                              cap_samples: int) -> int:
+        got = self.lib.azsp_export_dataset_device(self._h, first, n, C.c_void_p(planes_ptr), C.c_void_p(policies_ptr),
+                                                  C.c_void_p(values_ptr), cap_samples)
+        if got < 0:
+            L.check(int(got))
+        return int(got)
+
     @property
     def record_bytes(self) -> int:
         return int(self.lib.azsp_record_bytes(self.game_id))

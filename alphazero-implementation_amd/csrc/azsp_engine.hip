@@ -579,6 +579,24 @@ int64_t azsp_export_records_device(azsp_engine *e, int64_t first, int64_t n, voi
     return ns;
 }
 
+int64_t azsp_export_dataset_device(azsp_engine *e, int64_t first, int64_t n, float *planes, float *policies, float *values,
+                                   int64_t cap_samples) {
+    if (!e || first < 0 || n < 0 || !planes || !policies || !values) return fail(AZSP_ERR_ARG, "bad argument");
+    if (hipSetDevice(e->cfg.device) != hipSuccess) return fail(AZSP_ERR_HIP, "hipSetDevice failed");
+    if (first + n > e->h_res->episodes_total) return fail(AZSP_ERR_ARG, "episodes not emitted yet");
+    if (n == 0) return 0;
+    int64_t off[2];
+    if (hipMemcpy(&off[0], e->v.ep_offset + first, sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&off[1], e->v.ep_offset + first + n, sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(AZSP_ERR_HIP, "ep_offset copy failed");
+    const int64_t ns = off[1] - off[0];
+    if (ns > cap_samples) return fail(AZSP_ERR_ARG, "cap_samples %lld < %lld", (long long)cap_samples, (long long)ns);
+    // separate stream-ordered launch on the engine's main stream; the arena rows are final
+    launch_export_dataset(e->cfg.game, e->v, off[0], ns, planes, policies, values, e->stream);
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(AZSP_ERR_HIP, "export kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    return ns;
+}
+
 int azsp_get_stats(azsp_engine *e, azsp_stats *out) {
     if (!e || !out) return fail(AZSP_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->cfg.device));

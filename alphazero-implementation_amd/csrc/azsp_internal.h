@@ -92,6 +92,9 @@ void launch_root_stats(int game, const View &v, int32_t *counts, float *child_w,
 void launch_export_records(int game, const View &v, int64_t first_sample, int64_t n_samples, void *dst,
                            hipStream_t s);
 
+void launch_export_dataset(int game, const View &v, int64_t first_sample, int64_t n_samples, float *planes, float *pol,
+                           float *val, hipStream_t s);
+
 // ResNet evaluator (azsp_resnet.hip)
 struct ResNetDev;
 ResNetDev *resnet_create(int game, int blocks, int channels);

@@ -468,6 +468,25 @@ __global__ void k_export_records(View v, long long first, long long n, unsigned 
     for (int a = 0; a < G::A; ++a) pol[a] = v.out_policies[s * G::A + a];
 }
 
+// training tensors straight from the arena: BaseModel.format_dataset (base_model.py:61-67) with
+// ResNet._states_to_tensor (resnet.py:115-128): planes float32 [S][3][cells] = [empty, mine, theirs],
+// policies float32 [S][A] (float64 -> float32 as torch.FloatTensor does), values float32 [S]
+template <class G>
+__global__ void k_export_dataset(View v, long long first, long long n, float *planes, float *pol, float *val) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * G::CELLS) return;
+    const long long smp = i / G::CELLS;
+    const int cell = (int)(i % G::CELLS);
+    const long long src = first + smp;
+    const int8_t c = v.out_states[src * G::CELLS + cell];
+    float *pl = planes + smp * 3 * G::CELLS + cell;
+    pl[0] = c == 0 ? 1.0f : 0.0f;
+    pl[G::CELLS] = c == 1 ? 1.0f : 0.0f;
+    pl[2 * G::CELLS] = c == -1 ? 1.0f : 0.0f;
+    if (cell < G::A) pol[smp * G::A + cell] = (float)v.out_policies[src * G::A + cell];
+    if (cell == 0) val[smp] = (float)v.out_values[src];
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -510,6 +529,13 @@ void launch_export_records(int game, const View &v, int64_t first, int64_t n, vo
     if (n <= 0) return;
     GAME_SWITCH(game, hipLaunchKernelGGL(k_export_records<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v,
                                          (long long)first, (long long)n, (unsigned char *)dst));
+}
+
+void launch_export_dataset(int game, const View &v, int64_t first, int64_t n, float *planes, float *pol, float *val,
+                           hipStream_t s) {
+    if (n <= 0) return;
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_export_dataset<G>, dim3((unsigned)((n * G::CELLS + 255) / 256)), dim3(256), 0, s,
+                                         v, (long long)first, (long long)n, planes, pol, val));
 }
 
 }  // namespace azsp

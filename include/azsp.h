@@ -147,6 +147,13 @@ int  azsp_fetch_episodes(azsp_engine *e, int64_t first, int64_t n, int64_t *ep_o
  *   int8 state[cells] | int8 value | pad to 8 | double policy[A].  Returns the number of records. */
 int64_t azsp_export_records_device(azsp_engine *e, int64_t first, int64_t n, void *dev_dst, int64_t cap_records);
 int32_t azsp_record_bytes(int32_t game);
+/* Training tensors of episodes [first, first+n) written into caller-owned DEVICE memory, in the layout
+ * BaseModel.format_dataset produces (src/alphazero_simple/base_model.py:61-67 with
+ * ResNet._states_to_tensor, resnet.py:115-128; called at datamodule.py:134-142):
+ *   planes float32[S][3][cells] = [empty, ==+1, ==-1], policies float32[S][A], values float32[S].
+ * Returns S (number of samples) or < 0.  Replaces device->host->Python lists->np.stack->device. */
+int64_t azsp_export_dataset_device(azsp_engine *e, int64_t first, int64_t n, float *planes, float *policies,
+                                   float *values, int64_t cap_samples);
 
 int  azsp_get_stats(azsp_engine *e, azsp_stats *out);
 int  azsp_reset_stats(azsp_engine *e);

@@ -291,3 +291,29 @@ def test_device_record_export_matches_host_fetch(azsp):
             assert np.array_equal(s[k].reshape(6, 7), smp.state) and np.array_equal(p[k], smp.policy) and v[k] == smp.value
             k += 1
     assert torch.cuda.is_available()
+
+
+def test_device_dataset_equals_format_dataset_of_yielded_episodes(azsp):
+    """generate_dataset (tensors built on the GPU) == model.format_dataset applied, as the reference's
+    DataModule does (datamodule.py:134-142), to the episodes the generator yields under the same seed."""
+    import torch
+    from azsp.replay import DeviceReplayBuffer, generate_dataset
+    n, sims = 128, 30
+    cfg = azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1)
+    model = HashStub("connect4", 9)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg)
+    np.random.seed(4)
+    eps = list(gen.generate_episodes(model))
+    after = float(np.random.random_sample())
+    samples = [s for e in eps for s in e.samples]
+    host_ds = azsp.ResNet((6, 7), 7, 1, 32).format_dataset([s.state for s in samples], [s.policy for s in samples],
+                                                           [s.value for s in samples])
+    np.random.seed(4)
+    dev_ds = generate_dataset(gen, model)
+    assert float(np.random.random_sample()) == after
+    for h, d in zip(host_ds.tensors, dev_ds.tensors):
+        assert d.is_cuda and d.dtype == torch.float32 and torch.equal(h, d.cpu())
+    buf = DeviceReplayBuffer(history=2)
+    for _ in range(3):
+        buf.extend(dev_ds)
+    assert len(buf) == 2 * len(dev_ds) and buf.dataset().tensors[0].shape[0] == 2 * len(dev_ds)

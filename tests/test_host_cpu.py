@@ -102,3 +102,23 @@ def test_format_dataset_accepts_generator_output():
     assert x.shape == (2, 3, 6, 7) and pi.dtype == torch.float32 and z.tolist() == [1.0, -1.0]
     loss = net.training_step((x, pi, z), 0)
     assert torch.isfinite(loss)
+
+
+def test_episode_json_wire_format_roundtrip(tmp_path):
+    """save_episodes / load_episodes write and read the reference's file format
+    (datamodule.py:87-103): a JSON list of {"samples": [{"state","policy","value"}]}."""
+    import json
+    from azsp.replay import load_episodes, save_episodes
+    run = load_json("episodes_hash.json")["runs"][1]
+    eps = [azsp.Episode(samples=[azsp.Sample(np.array(s), np.array(p), v)
+                                 for s, p, v in zip(g["states"], g["policies"], g["values"])]) for g in run["episodes"]]
+    path = tmp_path / "sub" / "episodes_iter1.json"
+    save_episodes(path, eps)
+    raw = json.load(open(path))
+    assert isinstance(raw, list) and set(raw[0]) == {"samples"} and set(raw[0]["samples"][0]) == {"state", "policy", "value"}
+    back = load_episodes(path)
+    assert len(back) == len(eps)
+    for a, b in zip(eps, back):
+        assert len(a) == len(b)
+        for x, y in zip(a.samples, b.samples):
+            assert np.array_equal(x.state, y.state) and np.array_equal(x.policy, y.policy) and x.value == y.value
