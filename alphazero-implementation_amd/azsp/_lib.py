@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libazsp.so")
 GAME_CONNECT4, GAME_CONNECT2 = 0, 1
 EVAL_RESNET, EVAL_HASH, EVAL_HOST = 0, 1, 2
 FLAG_TIMING = 1
+FLAG_F16_SPLIT = 2
 ABI_VERSION = 1
 
 

@@ -20,11 +20,12 @@ from .mcts import configure_engine_for_model, default_device, engine_geometry_fo
 
 class EpisodeGenerator:
     def __init__(self, *, game, config: AlphaZeroConfig, device: int | None = None, timing: bool = False,
-                 n_groups: int = 0):
+                 n_groups: int = 0, f16_split: bool = False):
         self.game = game
         self.config = config
         self.device = device
         self.timing = timing
+        self.f16_split = f16_split    # device ResNet on the fp16 matrix pipe with split operands (fp32-class accuracy)
         self.n_groups = n_groups      # concurrent slot groups (HIP streams); 0 = automatic; never changes results
         self._engine: Engine | None = None
         self._engine_key = None
@@ -32,14 +33,14 @@ class EpisodeGenerator:
 
     def engine_for(self, model) -> Engine:
         blocks, ch, salt = engine_geometry_for_model(model)
-        key = (self.config.num_episodes, self.config.num_simulations, blocks, ch, salt)
+        key = (self.config.num_episodes, self.config.num_simulations, blocks, ch, salt, self.f16_split)
         if self._engine is None or key != self._engine_key:
             if self._engine is not None:
                 self._engine.close()
             dev = default_device() if self.device is None else self.device
             self._engine = Engine(self.game, self.config.num_episodes, self.config.num_simulations, device=dev,
                                   res_blocks=blocks, channels=ch, timing=self.timing, hash_salt=salt,
-                                  n_groups=self.n_groups)
+                                  n_groups=self.n_groups, f16_split=self.f16_split)
             self._engine_key = key
         configure_engine_for_model(self._engine, model)
         return self._engine

@@ -137,7 +137,8 @@ class ResNet(BaseModel):
         if self._azsp_engine is None:
             dev = int(os.environ.get("AZSP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
             self._azsp_engine = Engine("connect4", 4096, 1, device=dev, res_blocks=self.num_res_blocks,
-                                       channels=self.num_channels)
+                                       channels=self.num_channels,
+                                       f16_split=os.environ.get("AZSP_F16_SPLIT", "0") == "1")
         fp = self._fingerprint()
         if fp != self._azsp_fingerprint:
             self._azsp_engine.load_resnet(resnet_blob(self)[0])

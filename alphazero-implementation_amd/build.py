@@ -23,8 +23,9 @@ UNITS = {
     "azsp_tree.hip": ["-ffp-contract=off"],
     "azsp_engine.hip": ["-ffp-contract=off"],
     "azsp_resnet.hip": [],
+    "azsp_resnet_f16.hip": [],
 }
-HEADERS = ["azsp_internal.h", "azsp_games.h", os.path.join("..", "..", "include", "azsp.h")]
+HEADERS = ["azsp_internal.h", "azsp_games.h", "azsp_resnet_host.h", os.path.join("..", "..", "include", "azsp.h")]
 
 
 def hipcc() -> str:

@@ -286,7 +286,7 @@ size_t azsp_resnet_blob_floats(int32_t game, int32_t res_blocks, int32_t channel
 
 void azsp_destroy(azsp_engine *e) {
     if (!e) return;
-    hipSetDevice(e->cfg.device);
+    (void)hipSetDevice(e->cfg.device);
     for (int k = 0; k < MAX_GROUPS; ++k) if (e->gstream[k]) (void)hipStreamSynchronize(e->gstream[k]);
     for (auto &p : e->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -295,11 +295,11 @@ void azsp_destroy(azsp_engine *e) {
         if (e->gstream[k]) (void)hipStreamDestroy(e->gstream[k]);
     }
     if (e->net) resnet_destroy(e->net);
-    for (void *p : e->allocs) hipFree(p);
-    if (e->h_res) hipHostFree(e->h_res);
-    if (e->h_nleaf) hipHostFree(e->h_nleaf);
-    if (e->h_counters) hipHostFree(e->h_counters);
-    if (e->stream) hipStreamDestroy(e->stream);
+    for (void *p : e->allocs) (void)hipFree(p);
+    if (e->h_res) (void)hipHostFree(e->h_res);
+    if (e->h_nleaf) (void)hipHostFree(e->h_nleaf);
+    if (e->h_counters) (void)hipHostFree(e->h_counters);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
@@ -370,7 +370,7 @@ static int create_impl(azsp_engine *e) {
     e->h_mine.resize(N);
     e->h_theirs.resize(N);
     if (c.res_blocks > 0 && c.channels > 0) {
-        e->net = resnet_create(c.game, c.res_blocks, c.channels);
+        e->net = resnet_create(c.game, c.res_blocks, c.channels, (c.flags & AZSP_FLAG_F16_SPLIT) != 0);
         if (!e->net) return fail(AZSP_ERR_ARG, "unsupported ResNet geometry: %d blocks x %d channels", c.res_blocks, c.channels);
         e->evaluator = AZSP_EVAL_RESNET;
     }

@@ -97,7 +97,7 @@ void launch_export_dataset(int game, const View &v, int64_t first_sample, int64_
 
 // ResNet evaluator (azsp_resnet.hip)
 struct ResNetDev;
-ResNetDev *resnet_create(int game, int blocks, int channels);
+ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split);
 void resnet_destroy(ResNetDev *);
 int resnet_load(ResNetDev *, const float *blob, size_t n_floats, hipStream_t s);   // 0 ok
 size_t resnet_blob_floats(int game, int blocks, int channels);
@@ -105,5 +105,13 @@ size_t resnet_blob_floats(int game, int blocks, int channels);
 void resnet_forward(ResNetDev *, int game, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot,
                     const int32_t *n_leaf, int max_leaves, float *out_p, float *out_v, hipStream_t s);
 double resnet_flops_per_board(const ResNetDev *);
+
+// split-fp16 variant (azsp_resnet_f16.hip)
+struct ResNet16Dev;
+ResNet16Dev *resnet16_create(int game, int blocks, int channels);
+void resnet16_destroy(ResNet16Dev *);
+int resnet16_load(ResNet16Dev *, const float *blob, size_t n_floats, hipStream_t s);
+void resnet16_forward(ResNet16Dev *, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
+                      int max_leaves, float *out_p, float *out_v, hipStream_t s);
 
 }  // namespace azsp

@@ -25,14 +25,12 @@
 #include <vector>
 
 #include "azsp_internal.h"
+#include "azsp_resnet_host.h"
 
 namespace azsp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int POL_CH = 32;      // policy head conv channels (resnet.py:57)
-constexpr int VAL_CH = 3;       // value head conv channels  (resnet.py:66)
-constexpr float BN_EPS = 1e-5f;
 
 struct NetGeom {
     int rows, cols, cells, A;
@@ -49,6 +47,7 @@ struct ResNetDev {
     size_t o_stem_w, o_stem_b, o_conv_w, o_conv_b, o_pol_w, o_pol_b, o_val_w, o_val_b, o_fcp_w, o_fcp_b, o_fcv_w, o_fcv_b;
     size_t conv_w_stride, conv_b_stride;
     double flops_per_board = 0;
+    ResNet16Dev *f16 = nullptr;   // split-fp16 variant (AZSP_FLAG_F16_SPLIT)
 };
 
 struct NetParams {
@@ -415,29 +414,6 @@ size_t resnet_blob_floats(int game, int blocks, int channels) {
     return n;
 }
 
-struct ConvBN { const float *w, *b, *gamma, *beta, *mean, *var; int oc, ic, k; };
-
-static const float *take(const float *&p, size_t n) { const float *r = p; p += n; return r; }
-static ConvBN take_conv_bn(const float *&p, int oc, int ic, int k) {
-    ConvBN c;
-    c.oc = oc; c.ic = ic; c.k = k;
-    c.w = take(p, (size_t)oc * ic * k * k);
-    c.b = take(p, oc);
-    c.gamma = take(p, oc); c.beta = take(p, oc); c.mean = take(p, oc); c.var = take(p, oc);
-    return c;
-}
-// eval-mode BatchNorm folded into the convolution: y = (conv(x)+b-mean)*gamma/sqrt(var+eps)+beta
-static void fold(const ConvBN &c, std::vector<float> &w, std::vector<float> &b) {
-    const size_t per = (size_t)c.ic * c.k * c.k;
-    w.resize((size_t)c.oc * per);
-    b.resize(c.oc);
-    for (int o = 0; o < c.oc; ++o) {
-        const double s = (double)c.gamma[o] / sqrt((double)c.var[o] + (double)BN_EPS);
-        for (size_t i = 0; i < per; ++i) w[o * per + i] = (float)((double)c.w[o * per + i] * s);
-        b[o] = (float)(((double)c.b[o] - (double)c.mean[o]) * s + (double)c.beta[o]);
-    }
-}
-
 // B-fragment order for a KxK conv: dst[((tap*S + s)*64 + lane)*NTW + nt] = W[oc = nt*32 + (lane&31)][ic = 2s + (lane>>5)][tap]
 static void permute_conv(const std::vector<float> &w, int oc, int ic, int k, int S, int NTW, float *dst) {
     const int taps = k * k;
@@ -452,7 +428,7 @@ static void permute_conv(const std::vector<float> &w, int oc, int ic, int k, int
                 }
 }
 
-ResNetDev *resnet_create(int game, int blocks, int channels) {
+ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
     NetGeom g;
     if (!geom_for(game, blocks, channels, g)) return nullptr;
     ResNetDev *n = new ResNetDev();
@@ -480,12 +456,17 @@ ResNetDev *resnet_create(int game, int blocks, int channels) {
     const double C = g.C, cells = g.cells;
     n->flops_per_board = 2.0 * cells * (3 * 9 * C + 2.0 * blocks * C * C * 9 + C * POL_CH + C * 9 * VAL_CH) +
                          2.0 * (POL_CH * cells * g.A + VAL_CH * cells);
+    if (f16_split) {
+        n->f16 = resnet16_create(game, blocks, channels);
+        if (!n->f16) { (void)hipFree(n->d_blob); delete n; return nullptr; }
+    }
     return n;
 }
 
 void resnet_destroy(ResNetDev *n) {
     if (!n) return;
-    if (n->d_blob) hipFree(n->d_blob);
+    if (n->d_blob) (void)hipFree(n->d_blob);
+    if (n->f16) resnet16_destroy(n->f16);
     delete n;
 }
 
@@ -544,6 +525,7 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
     if ((size_t)(p - blob) != n_floats) return -2;
     if (hipMemcpyAsync(n->d_blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return -3;
     if (hipStreamSynchronize(s) != hipSuccess) return -4;
+    if (n->f16) return resnet16_load(n->f16, blob, n_floats, s);
     return 0;
 }
 
@@ -568,6 +550,7 @@ static void launch_forward(const NetParams &P, const u64 *mine, const u64 *their
 
 void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
                     int max_leaves, float *out_p, float *out_v, hipStream_t s) {
+    if (n->f16) { resnet16_forward(n->f16, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }
     NetParams P;
     const float *d = n->d_blob;
     P.stem_w = d + n->o_stem_w; P.stem_b = d + n->o_stem_b;

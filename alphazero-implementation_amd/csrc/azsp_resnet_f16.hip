@@ -1,0 +1,462 @@
+// Split-fp16 ("f16x2") variant of the fused ResNet inference kernel: the same network and the same
+// fusion as azsp_resnet.hip, but every fp32 operand is carried as two fp16 numbers and the
+// convolutions run on v_mfma_f32_32x32x16_f16 (16x the per-clock rate of the fp32 MFMA):
+//
+//     a = ah + al,  w = wh + wl   (ah = fp16(a), al = fp16(a - ah), same for w; power-of-two pre-scaling
+//                                  keeps the residuals out of the fp16 subnormal range)
+//     a*w  ~=  ah*wh + ah*wl + al*wh            (the dropped al*wl term is <= 2^-22 |a*w|)
+//
+// Products of fp16 numbers are exact in fp32 and the MFMA accumulates in fp32, so the result carries
+// ~22 mantissa bits -- fp32-class accuracy (tests: <= 1e-5 on p and v against the reference vectors, same
+// bound as the fp32 kernel) at 3 MFMAs of the 16x-rate instruction per 16-deep K slab = 5.3x fewer matrix
+// cycles.  Reduction order is fixed per output, so the kernel is batch-invariant like the fp32 one.
+//
+// Mapping: workgroup = 256 GEMM rows (6 boards) x all channels; waves form a WR x CT grid, wave (wr, wc)
+// owns MT = 8/WR row tiles x one 32-channel column tile (A fragments of a row tile are shared by the CT
+// waves of a row group through LDS; each weight fragment is loaded by WR waves only).  Activations live
+// in LDS as two fp16 planes [row][C+8] (row stride = odd number of 16-byte slots: conflict-free
+// ds_read_b128), residual in fp32 registers, single fp32 accumulator per tile.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "azsp_internal.h"
+#include "azsp_resnet_host.h"
+
+namespace azsp {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int F16_ROWS = 256;
+constexpr int ACT_SHIFT = 4;            // activations are stored scaled by 2^4
+constexpr float ACT_SCALE = 16.0f;
+constexpr int HB_STRIDE = 36;           // floats per row of the head-activation buffer
+
+struct Net16Params {
+    const h8 *stem_w, *conv_w, *pol_w, *val_w;
+    const float *stem_b, *conv_b, *pol_b, *val_b, *fcp_w, *fcp_b, *fcv_w, *fcv_b;
+    const float *conv_up, *conv_inv;   // per conv layer: 2^(ACT_SHIFT + k_l) and its inverse
+    float stem_inv, pol_inv, val_inv;
+    int conv_w_stride /* in h8 */, conv_b_stride, blocks;
+};
+
+struct ResNet16Dev {
+    int CT = 0, C = 0, blocks = 0, cells = 0, A = 0;
+    unsigned char *d_blob = nullptr;
+    size_t bytes = 0;
+    size_t o_stem_w, o_conv_w, o_pol_w, o_val_w;                                    // byte offsets of h8 arrays
+    size_t o_stem_b, o_conv_b, o_pol_b, o_val_b, o_fcp_w, o_fcp_b, o_fcv_w, o_fcv_b, o_up, o_inv;   // float arrays
+    size_t conv_w_stride = 0, conv_b_stride = 0;
+    float stem_inv = 1, pol_inv = 1, val_inv = 1;
+};
+
+__device__ __forceinline__ int cd_row16(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// conv over the LDS-resident split activations for NTILE row tiles of this wave and ONE column tile.
+//   w     : [tap][slab][ct][plane][64 lanes] h8, this wave's column tile `ct` selected by the caller via w + ...
+//   abyte : per tile, byte offset of (row, 8*half) inside a plane; vmask: 9-bit tap validity
+template <class G, int NTILE, int TAPS, int SL, int CT>
+__device__ __forceinline__ void conv16(f32x16 (&acc)[NTILE], const h8 *__restrict__ w, const unsigned char *plane_hi,
+                                       int plane_bytes, const int (&abyte)[NTILE], const uint32_t (&vmask)[NTILE],
+                                       int row_bytes, int zero_byte, int lane) {
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const int t9 = (TAPS == 9) ? tap : 4;
+        const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+        const unsigned char *arow[NTILE];
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i)
+            arow[i] = plane_hi + (((vmask[i] >> t9) & 1u) ? abyte[i] + (dy * G::COLS + dx) * row_bytes : zero_byte);
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) {
+            const h8 *wp = w + ((size_t)(tap * SL + sl) * CT) * 2 * 64 + lane;
+            const h8 bh = wp[0], bl = wp[64];
+#pragma unroll
+            for (int i = 0; i < NTILE; ++i) {
+                const h8 ah = *reinterpret_cast<const h8 *>(arow[i] + sl * 32);
+                const h8 al = *reinterpret_cast<const h8 *>(arow[i] + plane_bytes + sl * 32);
+                acc[i] = mfma16(ah, bh, acc[i]);
+                acc[i] = mfma16(ah, bl, acc[i]);
+                acc[i] = mfma16(al, bh, acc[i]);
+            }
+        }
+    }
+}
+
+template <class G, int CT>
+__global__ __launch_bounds__(64 * (CT == 1 ? 4 : 2) * CT, 2)
+void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
+                          const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
+                          float *__restrict__ out_p, float *__restrict__ out_v) {
+    constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
+    constexpr int WR = (CT == 1 ? 4 : 2), MT = 8 / WR, WAVES = WR * CT, NTHREADS = 64 * WAVES;
+    constexpr int TB = F16_ROWS / CELLS;
+    constexpr int CP = 32 * CT, SL = CP / 16, RS = CP + 8;       // row stride in halves
+    constexpr int ROW_BYTES = RS * 2, PLANE_BYTES = (F16_ROWS + 1) * ROW_BYTES, ZERO_BYTE = F16_ROWS * ROW_BYTES;
+    constexpr int PT = (MT + CT - 1) / CT;                       // head-conv row tiles per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    unsigned char *plane_hi = smem16;                            // [257][RS] halves, then the lo plane
+    _Float16 *act_hi = reinterpret_cast<_Float16 *>(smem16);
+    _Float16 *act_lo = reinterpret_cast<_Float16 *>(smem16 + PLANE_BYTES);
+    float *hb = reinterpret_cast<float *>(smem16);               // after the tower: [256][HB_STRIDE] head activations
+    float *part = hb + F16_ROWS * HB_STRIDE;                     // [256][8], then [TB][8] logits
+
+    const int n_leaf = *n_leaf_p;
+    const int board0 = blockIdx.x * TB;
+    if (board0 >= n_leaf) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r32 = lane & 31;
+    const int wr = wave / CT, wc = wave % CT;
+
+    for (int i = tid; i < RS; i += NTHREADS) { act_hi[F16_ROWS * RS + i] = (_Float16)0; act_lo[F16_ROWS * RS + i] = (_Float16)0; }
+
+    auto row_geom = [&](int r, uint32_t &vm, int &ab) {
+        const int b = r / CELLS, pos = r % CELLS, y = pos / COLS, x = pos % COLS;
+        const bool real = r < TB * CELLS && board0 + b < n_leaf;
+        uint32_t m = 0;
+        if (real)
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (yy >= 0 && yy < ROWS && xx >= 0 && xx < COLS) m |= 1u << t;
+            }
+        vm = m;
+        ab = r * ROW_BYTES + half * 16;
+    };
+    int abyte[MT];
+    uint32_t vmask[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) row_geom(wr * (MT * 32) + mt * 32 + r32, vmask[mt], abyte[mt]);
+
+    f32x16 acc[MT], xres[MT];
+    const int col = wc * 32 + r32;                                // output channel of this lane
+
+    // writes relu(acc*inv) as split fp16 planes (scaled by 2^ACT_SHIFT); optionally keeps the fp32 copy
+    auto store_act = [&](const f32x16 (&a)[MT], float inv, bool keep) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float o = fmaxf(a[mt][v] * inv, 0.0f);
+                if (keep) xres[mt][v] = o;
+                const float as = fminf(o * ACT_SCALE, 65504.0f);
+                const _Float16 hi = (_Float16)as;
+                const _Float16 lo = (_Float16)(as - (float)hi);
+                const int idx = (wr * (MT * 32) + mt * 32 + cd_row16(v, lane)) * RS + col;
+                act_hi[idx] = hi;
+                act_lo[idx] = lo;
+            }
+    };
+
+    // ---- stem: A fragments straight from the bitboards (values 0 / 2^ACT_SHIFT: lo plane is zero) ------
+    {
+        const float bias = P.stem_b[col];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mt][v] = bias;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const h8 *wp = P.stem_w + ((size_t)sl * CT + wc) * 2 * 64 + lane;
+            const h8 bh = wp[0], bl = wp[64];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = wr * (MT * 32) + mt * 32 + r32;
+                const int b = r / CELLS, pos = r % CELLS, y = pos / COLS, x = pos % COLS;
+                u64 bm = 0, bt = 0;
+                if (r < TB * CELLS && board0 + b < n_leaf) { const int slot = leaf_slot[board0 + b]; bm = mine[slot]; bt = theirs[slot]; }
+                h8 ah;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = 16 * sl + 8 * half + j;          // K index = tap*3 + plane
+                    const int tap = kk / 3, pl = kk % 3;
+                    float val = 0.0f;
+                    if (kk < 27 && ((vmask[mt] >> tap) & 1u)) {
+                        const int bit = G::bit_of(y + tap / 3 - 1, x + tap % 3 - 1);
+                        const int mi = (int)((bm >> bit) & 1ull), th = (int)((bt >> bit) & 1ull);
+                        val = (pl == 0 ? (1 - mi) * (1 - th) : (pl == 1 ? mi : th)) ? ACT_SCALE : 0.0f;
+                    }
+                    ah[j] = (_Float16)val;
+                }
+                acc[mt] = mfma16(ah, bh, acc[mt]);
+                acc[mt] = mfma16(ah, bl, acc[mt]);
+            }
+        }
+        store_act(acc, P.stem_inv, true);
+    }
+    __syncthreads();
+
+    // ---- residual blocks ---------------------------------------------------------------------------------
+    for (int layer = 0; layer < 2 * P.blocks; ++layer) {
+        const bool second = layer & 1;
+        const float bias = P.conv_b[(size_t)layer * P.conv_b_stride + col];
+        const float up = P.conv_up[layer];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mt][v] = second ? fmaf(xres[mt][v], up, bias) : bias;
+        conv16<G, MT, 9, SL, CT>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
+                                 abyte, vmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+        __syncthreads();
+        store_act(acc, P.conv_inv[layer], second);
+        __syncthreads();
+    }
+
+    // ---- heads: policy 1x1 and value 3x3 convs, one 32-wide column tile each; the row tiles of a row
+    //      group are dealt round-robin to its CT waves -----------------------------------------------------
+    f32x16 accp[PT], accv[PT];
+    int hbyte[PT], hrow0[PT];
+    uint32_t hmask[PT];
+    {
+        const float bp = P.pol_b[r32], bv = P.val_b[r32];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int mt = wc + i * CT;
+            hrow0[i] = mt < MT ? wr * (MT * 32) + mt * 32 : -1;
+            row_geom(hrow0[i] < 0 ? F16_ROWS - 1 : hrow0[i] + r32, hmask[i], hbyte[i]);
+            if (hrow0[i] < 0) hmask[i] = 0;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { accp[i][v] = bp; accv[i][v] = bv; }
+        }
+    }
+    conv16<G, PT, 1, SL, 1>(accp, P.pol_w, plane_hi, PLANE_BYTES, hbyte, hmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+    conv16<G, PT, 9, SL, 1>(accv, P.val_w, plane_hi, PLANE_BYTES, hbyte, hmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+        if (hrow0[i] >= 0) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = hrow0[i] + cd_row16(v, lane);
+                hb[row * HB_STRIDE + r32] = fmaxf(accp[i][v] * P.pol_inv, 0.0f);
+                if (r32 < VAL_CH) hb[row * HB_STRIDE + POL_CH + r32] = fmaxf(accv[i][v] * P.val_inv, 0.0f);
+            }
+        }
+    __syncthreads();
+
+    // ---- Linear layers, masked softmax, tanh: identical to the fp32 kernel --------------------------------
+    if (tid < TB * CELLS) {
+        const int pos = tid % CELLS;
+        float pa[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) pa[o] = 0.0f;
+        const float *hrow = hb + tid * HB_STRIDE;
+        for (int c = 0; c < POL_CH; ++c) {
+            const float h = hrow[c];
+            const float4 w0 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8);
+            const float4 w1 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8 + 4);
+            pa[0] = fmaf(h, w0.x, pa[0]); pa[1] = fmaf(h, w0.y, pa[1]); pa[2] = fmaf(h, w0.z, pa[2]); pa[3] = fmaf(h, w0.w, pa[3]);
+            pa[4] = fmaf(h, w1.x, pa[4]); pa[5] = fmaf(h, w1.y, pa[5]); pa[6] = fmaf(h, w1.z, pa[6]);
+        }
+        float pv = 0.0f;
+#pragma unroll
+        for (int c = 0; c < VAL_CH; ++c) pv = fmaf(hrow[POL_CH + c], P.fcv_w[c * CELLS + pos], pv);
+        pa[7] = pv;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) part[tid * 8 + o] = pa[o];
+    }
+    __syncthreads();
+    float *logits = part + F16_ROWS * 8;
+    if (tid < TB * 8) {
+        const int b = tid >> 3, o = tid & 7;
+        float sum = 0.0f;
+        for (int pos = 0; pos < CELLS; ++pos) sum += part[(b * CELLS + pos) * 8 + o];
+        logits[tid] = sum + (o < 7 ? (o < A ? P.fcp_b[o] : 0.0f) : P.fcv_b[0]);
+    }
+    __syncthreads();
+    if (tid < TB && board0 + tid < n_leaf) {
+        const int j = board0 + tid;
+        const int slot = leaf_slot[j];
+        const uint32_t legal = G::legal_mask(mine[slot], theirs[slot]);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < A; ++a) if ((legal >> a) & 1u) mx = fmaxf(mx, logits[tid * 8 + a]);
+        float ex[A], den = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A; ++a) { ex[a] = ((legal >> a) & 1u) ? expf(logits[tid * 8 + a] - mx) : 0.0f; den += ex[a]; }
+#pragma unroll
+        for (int a = 0; a < PSTRIDE; ++a) out_p[(size_t)j * PSTRIDE + a] = a < A ? ex[a < A ? a : 0] / den : 0.0f;
+        out_v[j] = tanhf(logits[tid * 8 + 7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host: scaling, splitting, permutation
+// ------------------------------------------------------------------------------------------------
+static int pow2_scale_for(const std::vector<float> &w) {       // k with max|w| * 2^k in [2^13, 2^14)
+    float mx = 0.0f;
+    for (float x : w) mx = fmaxf(mx, fabsf(x));
+    if (!(mx > 0.0f) || !isfinite(mx)) return 0;
+    int e;
+    frexpf(mx, &e);                  // mx = m * 2^e, m in [0.5, 1)
+    return 14 - e;
+}
+
+// dst[((((tap*SL + sl)*CTW + ct)*2 + plane)*64 + lane)*8 + j] = split(W[oc = ct*32 + (lane&31)][ic = 16 sl + 8 (lane>>5) + j][tap] * 2^k)
+static void permute_split(const std::vector<float> &w, int oc, int ic, int taps, int SL, int CTW, int k, _Float16 *dst) {
+    const float sc = ldexpf(1.0f, k);
+    for (int tap = 0; tap < taps; ++tap)
+        for (int sl = 0; sl < SL; ++sl)
+            for (int ct = 0; ct < CTW; ++ct)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int o = ct * 32 + (lane & 31), i = 16 * sl + 8 * (lane >> 5) + j;
+                        float val = 0.0f;
+                        if (o < oc && i < ic) val = w[((size_t)o * ic + i) * taps + tap] * sc;
+                        const _Float16 hi = (_Float16)val;
+                        const _Float16 lo = (_Float16)(val - (float)hi);
+                        const size_t base = ((((size_t)tap * SL + sl) * CTW + ct) * 2) * 64 * 8;
+                        dst[base + (size_t)lane * 8 + j] = hi;
+                        dst[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
+                    }
+}
+
+ResNet16Dev *resnet16_create(int game, int blocks, int channels) {
+    if (game != 0 || blocks < 0 || channels <= 0) return nullptr;
+    const int CT = (channels + 31) / 32;
+    if (CT < 1 || CT > 4) return nullptr;
+    ResNet16Dev *n = new ResNet16Dev();
+    n->CT = CT; n->C = channels; n->blocks = blocks; n->cells = Connect4::CELLS; n->A = Connect4::A;
+    const int SL = 2 * CT, CP = 32 * CT;
+    size_t off = 0;
+    auto reserve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    n->o_stem_w = reserve((size_t)2 * CT * 2 * 64 * 16);
+    n->conv_w_stride = (size_t)9 * SL * CT * 2 * 64;             // in h8 units
+    n->conv_b_stride = CP;
+    n->o_conv_w = reserve(n->conv_w_stride * 16 * 2 * blocks + 16);
+    n->o_pol_w = reserve((size_t)SL * 2 * 64 * 16);
+    n->o_val_w = reserve((size_t)9 * SL * 2 * 64 * 16);
+    n->o_stem_b = reserve(CP * 4);
+    n->o_conv_b = reserve((size_t)CP * 4 * 2 * blocks + 4);
+    n->o_pol_b = reserve(32 * 4);
+    n->o_val_b = reserve(32 * 4);
+    n->o_fcp_w = reserve((size_t)POL_CH * n->cells * 8 * 4);
+    n->o_fcp_b = reserve(8 * 4);
+    n->o_fcv_w = reserve((size_t)VAL_CH * n->cells * 4);
+    n->o_fcv_b = reserve(4 * 4);
+    n->o_up = reserve((size_t)(2 * blocks + 1) * 4);
+    n->o_inv = reserve((size_t)(2 * blocks + 1) * 4);
+    n->bytes = off;
+    if (hipMalloc((void **)&n->d_blob, off) != hipSuccess) { delete n; return nullptr; }
+    return n;
+}
+
+void resnet16_destroy(ResNet16Dev *n) {
+    if (!n) return;
+    if (n->d_blob) (void)hipFree(n->d_blob);
+    delete n;
+}
+
+int resnet16_load(ResNet16Dev *n, const float *blob, size_t n_floats, hipStream_t s) {
+    (void)n_floats;
+    const int CT = n->CT, SL = 2 * CT, C = n->C;
+    std::vector<unsigned char> host(n->bytes, 0);
+    std::vector<float> w, b;
+    auto H = [&](size_t o) { return reinterpret_cast<_Float16 *>(host.data() + o); };
+    auto F = [&](size_t o) { return reinterpret_cast<float *>(host.data() + o); };
+    const float *p = blob;
+    {   // stem: K index kk = tap*3 + plane (27 real, padded to 32 = 2 slabs); input planes are 0 / 2^ACT_SHIFT
+        ConvBN c = take_conv_bn(p, C, 3, 3);
+        fold(c, w, b);
+        const int k = pow2_scale_for(w);
+        const float sc = ldexpf(1.0f, k);
+        _Float16 *dst = H(n->o_stem_w);
+        for (int sl = 0; sl < 2; ++sl)
+            for (int ct = 0; ct < CT; ++ct)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int kk = 16 * sl + 8 * (lane >> 5) + j, o = ct * 32 + (lane & 31);
+                        float val = 0.0f;
+                        if (kk < 27 && o < C) val = w[((size_t)o * 3 + kk % 3) * 9 + kk / 3] * sc;
+                        const _Float16 hi = (_Float16)val, lo = (_Float16)(val - (float)hi);
+                        const size_t base = (((size_t)sl * CT + ct) * 2) * 64 * 8;
+                        dst[base + (size_t)lane * 8 + j] = hi;
+                        dst[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
+                    }
+        for (int o = 0; o < C; ++o) F(n->o_stem_b)[o] = b[o] * ldexpf(1.0f, ACT_SHIFT + k);
+        n->stem_inv = ldexpf(1.0f, -(ACT_SHIFT + k));
+    }
+    for (int l = 0; l < 2 * n->blocks; ++l) {
+        ConvBN c = take_conv_bn(p, C, C, 3);
+        fold(c, w, b);
+        const int k = pow2_scale_for(w);
+        permute_split(w, C, C, 9, SL, CT, k, H(n->o_conv_w) + (size_t)l * n->conv_w_stride * 8);
+        for (int o = 0; o < C; ++o) F(n->o_conv_b)[(size_t)l * n->conv_b_stride + o] = b[o] * ldexpf(1.0f, ACT_SHIFT + k);
+        F(n->o_up)[l] = ldexpf(1.0f, ACT_SHIFT + k);
+        F(n->o_inv)[l] = ldexpf(1.0f, -(ACT_SHIFT + k));
+    }
+    {
+        ConvBN c = take_conv_bn(p, POL_CH, C, 1);
+        fold(c, w, b);
+        const int k = pow2_scale_for(w);
+        permute_split(w, POL_CH, C, 1, SL, 1, k, H(n->o_pol_w));
+        for (int o = 0; o < POL_CH; ++o) F(n->o_pol_b)[o] = b[o] * ldexpf(1.0f, ACT_SHIFT + k);
+        n->pol_inv = ldexpf(1.0f, -(ACT_SHIFT + k));
+        const float *fw = take(p, (size_t)n->A * POL_CH * n->cells), *fb = take(p, n->A);
+        for (int c2 = 0; c2 < POL_CH; ++c2)
+            for (int pos = 0; pos < n->cells; ++pos)
+                for (int o = 0; o < n->A; ++o)
+                    F(n->o_fcp_w)[((size_t)c2 * n->cells + pos) * 8 + o] = fw[(size_t)o * POL_CH * n->cells + (size_t)c2 * n->cells + pos];
+        for (int o = 0; o < n->A; ++o) F(n->o_fcp_b)[o] = fb[o];
+    }
+    {
+        ConvBN c = take_conv_bn(p, VAL_CH, C, 3);
+        fold(c, w, b);
+        const int k = pow2_scale_for(w);
+        permute_split(w, VAL_CH, C, 9, SL, 1, k, H(n->o_val_w));
+        for (int o = 0; o < VAL_CH; ++o) F(n->o_val_b)[o] = b[o] * ldexpf(1.0f, ACT_SHIFT + k);
+        n->val_inv = ldexpf(1.0f, -(ACT_SHIFT + k));
+        const float *fw = take(p, (size_t)VAL_CH * n->cells), *fb = take(p, 1);
+        for (int i = 0; i < VAL_CH * n->cells; ++i) F(n->o_fcv_w)[i] = fw[i];
+        F(n->o_fcv_b)[0] = fb[0];
+    }
+    if (hipMemcpyAsync(n->d_blob, host.data(), host.size(), hipMemcpyHostToDevice, s) != hipSuccess) return -3;
+    if (hipStreamSynchronize(s) != hipSuccess) return -4;
+    return 0;
+}
+
+template <int CT>
+static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
+                     int max_leaves, float *out_p, float *out_v, hipStream_t s) {
+    using G = Connect4;
+    constexpr int WR = (CT == 1 ? 4 : 2), WAVES = WR * CT, RS = 32 * CT + 8, TB = F16_ROWS / G::CELLS;
+    constexpr size_t planes = (size_t)2 * (F16_ROWS + 1) * RS * 2;
+    constexpr size_t heads = ((size_t)F16_ROWS * HB_STRIDE + F16_ROWS * 8 + TB * 8) * 4;
+    const size_t lds = planes > heads ? planes : heads;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward_f16<G, CT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[dev] = true;
+    }
+    const int grid = (max_leaves + TB - 1) / TB;
+    hipLaunchKernelGGL((k_resnet_forward_f16<G, CT>), dim3(grid), dim3(64 * WAVES), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
+}
+
+void resnet16_forward(ResNet16Dev *n, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
+                      int max_leaves, float *out_p, float *out_v, hipStream_t s) {
+    Net16Params P;
+    unsigned char *d = n->d_blob;
+    auto H = [&](size_t o) { return reinterpret_cast<const h8 *>(d + o); };
+    auto F = [&](size_t o) { return reinterpret_cast<const float *>(d + o); };
+    P.stem_w = H(n->o_stem_w); P.conv_w = H(n->o_conv_w); P.pol_w = H(n->o_pol_w); P.val_w = H(n->o_val_w);
+    P.stem_b = F(n->o_stem_b); P.conv_b = F(n->o_conv_b); P.pol_b = F(n->o_pol_b); P.val_b = F(n->o_val_b);
+    P.fcp_w = F(n->o_fcp_w); P.fcp_b = F(n->o_fcp_b); P.fcv_w = F(n->o_fcv_w); P.fcv_b = F(n->o_fcv_b);
+    P.conv_up = F(n->o_up); P.conv_inv = F(n->o_inv);
+    P.stem_inv = n->stem_inv; P.pol_inv = n->pol_inv; P.val_inv = n->val_inv;
+    P.conv_w_stride = (int)n->conv_w_stride; P.conv_b_stride = (int)n->conv_b_stride; P.blocks = n->blocks;
+    switch (n->CT) {
+        case 1: launch16<1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); break;
+        case 2: launch16<2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); break;
+        case 3: launch16<3>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); break;
+        default: launch16<4>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); break;
+    }
+}
+
+}  // namespace azsp

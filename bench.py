@@ -30,6 +30,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: fp16/bf16 MFMA, dense
 
 
 def resnet_flops_per_board(blocks: int, ch: int, cells: int = 42, actions: int = 7) -> float:
@@ -67,6 +68,8 @@ def main() -> None:
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--cpu-slots", type=int, default=48, help="concurrent games of the CPU baseline sample")
     ap.add_argument("--groups", type=int, default=0, help="concurrent slot groups / HIP streams per GPU (0 = auto)")
+    ap.add_argument("--precision", choices=["f32", "f16x2"], default="f32",
+                    help="inference arithmetic: exact fp32 MFMA, or fp16 MFMA with split (hi+lo) operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -100,7 +103,7 @@ def main() -> None:
     cfg = azsp.AlphaZeroConfig(batch_size=32, num_iterations=1, num_simulations=args.sims, num_episodes=args.slots,
                                num_iters_for_train_history=1, epochs=1)
     gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg, device=local_rank, timing=True,
-                                n_groups=args.groups)
+                                n_groups=args.groups, f16_split=args.precision == "f16x2")
 
     def step(seed: int):
         np.random.seed(seed)                   # independent replica per rank (SURVEY 8e mode B)
@@ -150,12 +153,13 @@ def main() -> None:
         union_ms = st["infer_union_ms"] if st["infer_union_ms"] > 0 else st["infer_ms"]
         overlap = st["infer_ms"] / union_ms if union_ms > 0 else 1.0
         achieved = fpb * st["infer_boards"] / (union_ms * 1e-3) / 1e12 if union_ms > 0 else 0.0
+        peak = PEAK_FP32_MATRIX_TFLOPS if args.precision == "f32" else PEAK_F16_MATRIX_TFLOPS
         out = {
             "metric": "self-play episodes/sec (Connect-4, 100 sims/move)" if args.sims == 100 else
                       f"self-play episodes/sec (Connect-4, {args.sims} sims/move)",
             "value": episodes / dt, "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (empty-board starts, random-weight net, seeded RNG)",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x2 (fp32 operands split into two fp16, fp32 accumulate)", "data": "synthetic (empty-board starts, random-weight net, seeded RNG)",
             "config": {"workload": f"Connect-4 self-play, ResNet {args.channels}ch/{args.blocks}blk random weights, "
                                    f"{args.sims} sims/move, {args.slots} concurrent games per GPU, first "
                                    f"{args.slots} completions per GPU per step",
@@ -163,7 +167,7 @@ def main() -> None:
                        "episodes": episodes, "samples": samples,
                        "mean_plies_per_episode": samples / max(episodes, 1)},
             "roofline": {"bound": "mfma", "kernel": "k_resnet_forward", "achieved": achieved,
-                         "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": None, "flops_per_board": fpb, "boards_per_launch": boards_per_launch,
                          "avg_launch_ms": avg_ms, "launches": launches, "concurrent_launches": overlap,
                          "busy_ms": union_ms, "infer_share_of_wall": union_ms * 1e-3 / dt if dt > 0 else None},

@@ -45,6 +45,10 @@ enum { AZSP_OK = 0, AZSP_ERR_ARG = -1, AZSP_ERR_HIP = -2, AZSP_ERR_STATE = -3, A
        AZSP_ERR_NOMEM = -5 };
 
 #define AZSP_FLAG_TIMING 1u      /* record HIP events around every kernel class (azsp_get_stats) */
+#define AZSP_FLAG_F16_SPLIT 2u   /* device ResNet on the fp16 matrix pipe with every fp32 operand split into
+                                    two fp16 numbers (hi*hi + hi*lo + lo*hi, fp32 accumulate): fp32-class
+                                    accuracy (<= 1e-5 on p, v), 3 MFMAs at 16x the fp32-MFMA rate.  Without
+                                    the flag the network runs on v_mfma_f32_32x32x2_f32 (exact fp32).     */
 
 typedef struct azsp_config {
     uint32_t struct_size;    /* sizeof(azsp_config), for forward compatibility                       */

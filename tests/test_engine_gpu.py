@@ -148,8 +148,9 @@ def _golden_net(tag):
     return z, sd
 
 
+@pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
 @pytest.mark.parametrize("tag", ["s", "m"])
-def test_resnet_forward_matches_reference_vectors(azsp, tag):
+def test_resnet_forward_matches_reference_vectors(azsp, tag, f16):
     """Fused MFMA tower vs ResNet.predict of the reference on torch-CPU.  fp32 everywhere, different
     summation order and BN folding -> tolerance 1e-5 absolute on probabilities and tanh values."""
     from azsp.weights import resnet_blob
@@ -157,7 +158,7 @@ def test_resnet_forward_matches_reference_vectors(azsp, tag):
     blob, blocks, ch = resnet_blob({k: v for k, v in sd.items() if "num_batches_tracked" not in k})
     assert [blocks, ch] == z[f"{tag}_arch"].tolist()
     boards = z["boards"]
-    with _engine(azsp, "connect4", 64, 1, res_blocks=blocks, channels=ch) as e:
+    with _engine(azsp, "connect4", 64, 1, res_blocks=blocks, channels=ch, f16_split=f16) as e:
         e.load_resnet(blob)
         p, v = e.predict(boards)
         p2, v2 = e.predict(boards[::-1].copy())            # batch-invariance: other order, other tiles
@@ -168,7 +169,8 @@ def test_resnet_forward_matches_reference_vectors(azsp, tag):
     assert np.all(np.abs(p.sum(axis=1) - 1) < 1e-6)
 
 
-def test_resnet_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp):
+@pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
+def test_resnet_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp, f16):
     """End-to-end with the real network: the C oracle runs the reference algorithm on the CPU but asks
     the DEVICE kernel for (P, V) through the C ABI; the engine runs everything on the GPU.  Both see
     identical floats, so visit counts, moves, pi and z must be bit-identical."""
@@ -176,7 +178,7 @@ def test_resnet_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp):
     _, sd = _golden_net("m")
     blob, blocks, ch = resnet_blob({k: v for k, v in sd.items() if "num_batches_tracked" not in k})
     n, sims, seed = 32, 50, 21
-    with _engine(azsp, "connect4", 64, 1, res_blocks=blocks, channels=ch) as pe:
+    with _engine(azsp, "connect4", 64, 1, res_blocks=blocks, channels=ch, f16_split=f16) as pe:
         pe.load_resnet(blob)
         cb = co.make_predict_cb(lambda bs: pe.predict(np.stack(bs)), (6, 7), 7)
         ref = co.generate("connect4", sims, n, seed=seed, predict_cb=cb, trace=False)
@@ -186,7 +188,8 @@ def test_resnet_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp):
             return {k: v for k, v in sd.items() if "num_batches_tracked" not in k}
 
     np.random.seed(seed)
-    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1),
+                                f16_split=f16)
     eps = list(gen.generate_episodes(Net()))
     assert float(np.random.random_sample()) == ref["next_uniform"]
     for e, ep in enumerate(eps):
@@ -196,11 +199,13 @@ def test_resnet_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp):
         assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()
 
 
-@pytest.mark.parametrize("blocks,ch", [(2, 32), (1, 16), (3, 48), (2, 128), (8, 128), (1, 100)])
-def test_resnet_model_predict_uses_device_kernel(azsp, blocks, ch):
+@pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
+@pytest.mark.parametrize("blocks,ch", [(2, 32), (1, 16), (3, 48), (2, 128), (8, 128), (1, 100), (4, 64), (2, 96)])
+def test_resnet_model_predict_uses_device_kernel(azsp, blocks, ch, f16, monkeypatch):
     """azsp.ResNet.predict (HIP kernel) vs the same module's PyTorch forward on the CPU, for every
     channel-tile count the kernel is instantiated for (C padded to 32/64/128).  Tolerance 1e-5."""
     import torch
+    monkeypatch.setenv("AZSP_F16_SPLIT", "1" if f16 else "0")
     torch.manual_seed(blocks * 1000 + ch)
     net = azsp.ResNet((6, 7), 7, blocks, ch)
     with torch.no_grad():                          # non-trivial BatchNorm statistics
@@ -219,7 +224,9 @@ def test_resnet_model_predict_uses_device_kernel(azsp, blocks, ch):
         mask = torch.tensor([rules.valid_moves(b) for b in boards])
         pt = torch.softmax(logits.masked_fill(mask == 0, float("-inf")), dim=1).numpy()
         vt = torch.tanh(vl).numpy()
-    assert np.max(np.abs(np.stack(p) - pt)) < 1e-5 and np.max(np.abs(np.array(v) - vt)) < 1e-5
+    err_p, err_v = np.max(np.abs(np.stack(p) - pt)), np.max(np.abs(np.array(v) - vt))
+    print(f"blocks={blocks} ch={ch} f16x2={f16}: max |dp| = {err_p:.2e}, max |dv| = {err_v:.2e}")
+    assert err_p < 1e-5 and err_v < 1e-5
     clone = net.get_inference_clone()
     assert clone._azsp_engine is None and net._azsp_engine is not None
     with torch.no_grad():                          # weights change -> next predict re-uploads
