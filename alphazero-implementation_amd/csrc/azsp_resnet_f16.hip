@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int F16_ROWS = 256;
 constexpr int ACT_SHIFT = 4;            // activations are stored scaled by 2^4
 constexpr float ACT_SCALE = 16.0f;
-constexpr int HB_STRIDE = 36;           // floats per row of the head-activation buffer
+constexpr int HB_STRIDE = 37;           // floats per row of the head-activation buffer (odd: conflict-free column reads)
 
 struct Net16Params {
     const h8 *stem_w, *conv_w, *pol_w, *val_w;
@@ -89,13 +89,13 @@ __device__ __forceinline__ void conv16(f32x16 (&acc)[NTILE], const h8 *__restric
     }
 }
 
-template <class G, int CT>
-__global__ __launch_bounds__(64 * (CT == 1 ? 4 : 2) * CT, 2)
+template <class G, int CT, int WR>
+__global__ __launch_bounds__(64 * WR * CT, 2)
 void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
                           const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
                           float *__restrict__ out_p, float *__restrict__ out_v) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
-    constexpr int WR = (CT == 1 ? 4 : 2), MT = 8 / WR, WAVES = WR * CT, NTHREADS = 64 * WAVES;
+    constexpr int MT = 8 / WR, WAVES = WR * CT, NTHREADS = 64 * WAVES;
     constexpr int TB = F16_ROWS / CELLS;
     constexpr int CP = 32 * CT, SL = CP / 16, RS = CP + 8;       // row stride in halves
     constexpr int ROW_BYTES = RS * 2, PLANE_BYTES = (F16_ROWS + 1) * ROW_BYTES, ZERO_BYTE = F16_ROWS * ROW_BYTES;
@@ -419,11 +419,11 @@ int resnet16_load(ResNet16Dev *n, const float *blob, size_t n_floats, hipStream_
     return 0;
 }
 
-template <int CT>
+template <int CT, int WR>
 static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
                      int max_leaves, float *out_p, float *out_v, hipStream_t s) {
     using G = Connect4;
-    constexpr int WR = (CT == 1 ? 4 : 2), WAVES = WR * CT, RS = 32 * CT + 8, TB = F16_ROWS / G::CELLS;
+    constexpr int WAVES = WR * CT, RS = 32 * CT + 8, TB = F16_ROWS / G::CELLS;
     constexpr size_t planes = (size_t)2 * (F16_ROWS + 1) * RS * 2;
     constexpr size_t heads = ((size_t)F16_ROWS * HB_STRIDE + F16_ROWS * 8 + TB * 8) * 4;
     const size_t lds = planes > heads ? planes : heads;
@@ -431,12 +431,12 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, c
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward_f16<G, CT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward_f16<G, CT, WR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev] = true;
     }
     const int grid = (max_leaves + TB - 1) / TB;
-    hipLaunchKernelGGL((k_resnet_forward_f16<G, CT>), dim3(grid), dim3(64 * WAVES), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
+    hipLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR>), dim3(grid), dim3(64 * WAVES), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
 }
 
 void resnet16_forward(ResNet16Dev *n, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
@@ -451,12 +451,16 @@ void resnet16_forward(ResNet16Dev *n, const u64 *mine, const u64 *theirs, const 
     P.conv_up = F(n->o_up); P.conv_inv = F(n->o_inv);
     P.stem_inv = n->stem_inv; P.pol_inv = n->pol_inv; P.val_inv = n->val_inv;
     P.conv_w_stride = (int)n->conv_w_stride; P.conv_b_stride = (int)n->conv_b_stride; P.blocks = n->blocks;
+    // wave grid WR x CT over the 256-row x C tile (tuning knob AZSP_F16_WR; results do not depend on it)
+    static const int wr_env = [] { const char *e = getenv("AZSP_F16_WR"); return e ? atoi(e) : 0; }();
+#define L16(CTV, WRV) launch16<CTV, WRV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
     switch (n->CT) {
-        case 1: launch16<1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); break;
-        case 2: launch16<2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); break;
-        case 3: launch16<3>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); break;
-        default: launch16<4>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); break;
+        case 1: if (wr_env == 8) L16(1, 8); else L16(1, 4); break;
+        case 2: if (wr_env == 4) L16(2, 4); else L16(2, 2); break;
+        case 3: L16(3, 2); break;
+        default: if (wr_env == 4) L16(4, 4); else L16(4, 2); break;
     }
+#undef L16
 }
 
 }  // namespace azsp

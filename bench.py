@@ -10,9 +10,14 @@ simulations per move, random-weight ResNet(`--blocks`, `--channels`), run until 
 completed (reference stop rule), examples copied to the host, and -- for N > 1 -- the packed
 (s, pi, z) records all-gathered over RCCL.  Games shard over GPUs with no other traffic (weak scaling).
 
-The JSON line carries the MFMA roofline of the dominant kernel (k_resnet_forward, timed with HIP
-events on the engine's own stream inside the timed region) and a CPU baseline: the oracle's
-pure-Python/torch-CPU port of the reference path timed on this box's host cores (rank 0, N=1 only)."""
+The headline (`value`, `roofline`) is measured with the inference kernel in exact fp32
+(v_mfma_f32_32x32x2_f32, `dtype` "f32").  Unless `--single`, the same workload is then measured once more
+with the split-fp16 inference kernel (fp32 operands carried as two fp16 numbers, fp32 accumulate; same
+accuracy bound in the tests) and reported under `"f16x2"`; `--precision f16x2` makes that the headline.
+
+The JSON line carries the MFMA roofline of the dominant kernel (timed with HIP events on the engine's
+own streams inside the timed region) and a CPU baseline: the oracle's pure-Python/torch-CPU port of the
+reference path timed on this box's host cores (rank 0, N=1 only)."""
 from __future__ import annotations
 
 import argparse
@@ -29,8 +34,10 @@ for p in (ROOT, os.path.join(ROOT, "alphazero-implementation_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_F16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: fp16/bf16 MFMA, dense
+PEAK_TFLOPS = {"f32": 157.3,      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+               "f16x2": 2500.0}   # MI355X_MICROARCH.md: fp16/bf16 MFMA, dense
+DTYPE = {"f32": "f32", "f16x2": "f16x2 (fp32 operands split into two fp16, fp32 accumulate)"}
+KERNEL = {"f32": "k_resnet_forward", "f16x2": "k_resnet_forward_f16"}
 
 
 def resnet_flops_per_board(blocks: int, ch: int, cells: int = 42, actions: int = 7) -> float:
@@ -40,7 +47,18 @@ def resnet_flops_per_board(blocks: int, ch: int, cells: int = 42, actions: int =
     return 2.0 * (conv + fc)
 
 
-def cpu_baseline(blocks: int, ch: int, sims: int, slots: int, state_dict) -> dict:
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate
+    --pmc passes, FETCH_SIZE doubled per the gfx950 correction); None if no summary is present."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(sims: int, slots: int, state_dict) -> dict:
     """oracle/az_oracle.py + oracle/resnet_ref.py (port of the reference's Python/torch-CPU path)."""
     from oracle import az_oracle as oz
     from oracle.resnet_ref import ResNetRef
@@ -68,8 +86,8 @@ def main() -> None:
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--cpu-slots", type=int, default=48, help="concurrent games of the CPU baseline sample")
     ap.add_argument("--groups", type=int, default=0, help="concurrent slot groups / HIP streams per GPU (0 = auto)")
-    ap.add_argument("--precision", choices=["f32", "f16x2"], default="f32",
-                    help="inference arithmetic: exact fp32 MFMA, or fp16 MFMA with split (hi+lo) operands")
+    ap.add_argument("--precision", choices=["f32", "f16x2"], default="f32", help="inference arithmetic of the headline")
+    ap.add_argument("--single", action="store_true", help="measure only --precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -102,81 +120,95 @@ def main() -> None:
     net.eval()
     cfg = azsp.AlphaZeroConfig(batch_size=32, num_iterations=1, num_simulations=args.sims, num_episodes=args.slots,
                                num_iters_for_train_history=1, epochs=1)
-    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg, device=local_rank, timing=True,
-                                n_groups=args.groups, f16_split=args.precision == "f16x2")
-
-    def step(seed: int):
-        np.random.seed(seed)                   # independent replica per rank (SURVEY 8e mode B)
-        eps = list(gen.generate_episodes(net))
-        n_samples = sum(len(e) for e in eps)
-        gathered = all_gather_records(gen, dist, world, coll_dev) if world > 1 else None
-        return len(eps), n_samples, gathered
+    fpb = resnet_flops_per_board(args.blocks, args.channels)
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        step(1000 * (w + 1) + rank)
-    eng = gen.engine_for(net)
-    eng.reset_stats()
-    fence()
-    t0 = time.perf_counter()
-    episodes = samples = gathered_records = 0
-    for k in range(args.steps):
-        e, s, g = step(10 * k + rank)
-        episodes += e
-        samples += s
-        if g is not None:
-            gathered_records += sum(int(x.shape[0]) for x in g)
-    fence()
-    dt = time.perf_counter() - t0
-    st = eng.stats()
-    if dist is not None:
-        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        tot = torch.tensor([episodes, samples], device=coll_dev, dtype=torch.int64)
-        dist.all_reduce(tot)
-        episodes, samples = int(tot[0]), int(tot[1])
-        if gathered_records != samples:
-            raise SystemExit(f"rank {rank}: all-gather delivered {gathered_records} records, expected {samples}")
+    def measure(precision: str) -> dict:
+        gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg, device=local_rank, timing=True,
+                                    n_groups=args.groups, f16_split=precision == "f16x2")
 
-    if rank == 0:
-        fpb = resnet_flops_per_board(args.blocks, args.channels)
+        def step(seed: int):
+            np.random.seed(seed)               # independent replica per rank (SURVEY 8e mode B)
+            eps = list(gen.generate_episodes(net))
+            gathered = all_gather_records(gen, dist, world, coll_dev) if world > 1 else None
+            return len(eps), sum(len(e) for e in eps), gathered
+
+        for w in range(args.warmup):
+            step(1000 * (w + 1) + rank)
+        eng = gen.engine_for(net)
+        eng.reset_stats()
+        fence()
+        t0 = time.perf_counter()
+        episodes = samples = gathered_records = 0
+        for k in range(args.steps):
+            e, s, g = step(10 * k + rank)
+            episodes += e
+            samples += s
+            if g is not None:
+                gathered_records += sum(int(x.shape[0]) for x in g)
+        fence()
+        dt = time.perf_counter() - t0
+        st = eng.stats()
+        if dist is not None:
+            t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            tot = torch.tensor([episodes, samples], device=coll_dev, dtype=torch.int64)
+            dist.all_reduce(tot)
+            episodes, samples = int(tot[0]), int(tot[1])
+            if gathered_records != samples:
+                raise SystemExit(f"rank {rank}: all-gather delivered {gathered_records} records, expected {samples}")
+        eng.close()
         launches = max(int(st["infer_launches"]), 1)
         avg_ms = st["infer_ms"] / launches
-        boards_per_launch = st["infer_boards"] / launches
-        # Launches of different slot groups run concurrently on separate streams, so the rate is taken over
-        # the union of the launch intervals: flops per launch / (average duration / overlap factor).
+        # Launches of different slot groups run concurrently on separate streams, so the rate is taken over the
+        # union of the launch intervals: flops per launch / (average launch duration / overlap factor).
         union_ms = st["infer_union_ms"] if st["infer_union_ms"] > 0 else st["infer_ms"]
         overlap = st["infer_ms"] / union_ms if union_ms > 0 else 1.0
         achieved = fpb * st["infer_boards"] / (union_ms * 1e-3) / 1e12 if union_ms > 0 else 0.0
-        peak = PEAK_FP32_MATRIX_TFLOPS if args.precision == "f32" else PEAK_F16_MATRIX_TFLOPS
-        out = {
-            "metric": "self-play episodes/sec (Connect-4, 100 sims/move)" if args.sims == 100 else
-                      f"self-play episodes/sec (Connect-4, {args.sims} sims/move)",
-            "value": episodes / dt, "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x2 (fp32 operands split into two fp16, fp32 accumulate)", "data": "synthetic (empty-board starts, random-weight net, seeded RNG)",
-            "config": {"workload": f"Connect-4 self-play, ResNet {args.channels}ch/{args.blocks}blk random weights, "
-                                   f"{args.sims} sims/move, {args.slots} concurrent games per GPU, first "
-                                   f"{args.slots} completions per GPU per step",
-                       "slots_per_gpu": args.slots, "sims": args.sims, "parallelism": f"game-sharded x{world}",
-                       "episodes": episodes, "samples": samples,
-                       "mean_plies_per_episode": samples / max(episodes, 1)},
-            "roofline": {"bound": "mfma", "kernel": "k_resnet_forward", "achieved": achieved,
-                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "flops_per_board": fpb, "boards_per_launch": boards_per_launch,
-                         "avg_launch_ms": avg_ms, "launches": launches, "concurrent_launches": overlap,
-                         "busy_ms": union_ms, "infer_share_of_wall": union_ms * 1e-3 / dt if dt > 0 else None},
+        peak = PEAK_TFLOPS[precision]
+        return {
+            "value": episodes / dt, "unit": "episodes/s", "ms_per_step": 1e3 * dt / max(args.steps, 1), "dtype": DTYPE[precision],
+            "episodes": episodes, "samples": samples,
+            "roofline": {"bound": "mfma", "kernel": KERNEL[precision], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": pmc_traffic(KERNEL[precision]), "flops_per_board": fpb,
+                         "boards_per_launch": st["infer_boards"] / launches, "avg_launch_ms": avg_ms, "launches": launches,
+                         "concurrent_launches": overlap, "busy_ms": union_ms,
+                         "infer_share_of_wall": union_ms * 1e-3 / dt if dt > 0 else None},
             "tree": {"select_ms": st["select_ms"], "expand_ms": st["expand_ms"], "play_ms": st["play_ms"],
                      "rounds": int(st["rounds"]), "evals": int(st["evals"]),
                      "terminal_leaves": int(st["terminal_leaves"]), "path_nodes": int(st["path_nodes"])},
         }
+
+    head = measure(args.precision)
+    other = None
+    if not args.single:
+        other = measure("f16x2" if args.precision == "f32" else "f32")
+
+    if rank == 0:
+        out = {
+            "metric": "self-play episodes/sec (Connect-4, 100 sims/move)" if args.sims == 100 else
+                      f"self-play episodes/sec (Connect-4, {args.sims} sims/move)",
+            "value": head["value"], "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": head["dtype"], "data": "synthetic (empty-board starts, random-weight net, seeded RNG)",
+            "config": {"workload": f"Connect-4 self-play, ResNet {args.channels}ch/{args.blocks}blk random weights, "
+                                   f"{args.sims} sims/move, {args.slots} concurrent games per GPU, first "
+                                   f"{args.slots} completions per GPU per step",
+                       "slots_per_gpu": args.slots, "sims": args.sims, "parallelism": f"game-sharded x{world}",
+                       "episodes": head["episodes"], "samples": head["samples"],
+                       "mean_plies_per_episode": head["samples"] / max(head["episodes"], 1)},
+            "roofline": head["roofline"], "tree": head["tree"],
+        }
+        if other is not None:
+            key = "f16x2" if args.precision == "f32" else "f32"
+            out[key] = {k: other[k] for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "tree")}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.blocks, args.channels, args.sims, args.cpu_slots, net.state_dict())
+            out["cpu_baseline"] = cpu_baseline(args.sims, args.cpu_slots, net.state_dict())
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
