@@ -455,8 +455,8 @@ void resnet16_forward(ResNet16Dev *n, const u64 *mine, const u64 *theirs, const 
     static const int wr_env = [] { const char *e = getenv("AZSP_F16_WR"); return e ? atoi(e) : 0; }();
 #define L16(CTV, WRV) launch16<CTV, WRV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
     switch (n->CT) {
-        case 1: if (wr_env == 8) L16(1, 8); else L16(1, 4); break;
-        case 2: if (wr_env == 4) L16(2, 4); else L16(2, 2); break;
+        case 1: if (wr_env == 8 || (!wr_env && max_leaves <= 768)) L16(1, 8); else L16(1, 4); break;
+        case 2: if (wr_env == 4 || (!wr_env && max_leaves <= 768)) L16(2, 4); else L16(2, 2); break;   // small batch: more waves per board
         case 3: L16(3, 2); break;
         default: if (wr_env == 4) L16(4, 4); else L16(4, 2); break;
     }
