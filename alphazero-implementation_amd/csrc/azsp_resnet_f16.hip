@@ -62,7 +62,7 @@ __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
 // conv over the LDS-resident split activations for NTILE row tiles of this wave and ONE column tile.
 //   w     : [tap][slab][ct][plane][64 lanes] h8, this wave's column tile `ct` selected by the caller via w + ...
 //   abyte : per tile, byte offset of (row, 8*half) inside a plane; vmask: 9-bit tap validity
-template <class G, int NTILE, int TAPS, int SL, int CT>
+template <class G, int NTILE, int TAPS, int SL, int CT, int ABL = 0>
 __device__ __forceinline__ void conv16(f32x16 (&acc)[NTILE], const h8 *__restrict__ w, const unsigned char *plane_hi,
                                        int plane_bytes, const int (&abyte)[NTILE], const uint32_t (&vmask)[NTILE],
                                        int row_bytes, int zero_byte, int lane) {
@@ -75,12 +75,12 @@ __device__ __forceinline__ void conv16(f32x16 (&acc)[NTILE], const h8 *__restric
             arow[i] = plane_hi + (((vmask[i] >> t9) & 1u) ? abyte[i] + (dy * G::COLS + dx) * row_bytes : zero_byte);
 #pragma unroll
         for (int sl = 0; sl < SL; ++sl) {
-            const h8 *wp = w + ((size_t)(tap * SL + sl) * CT) * 2 * 64 + lane;
+            const h8 *wp = w + ((size_t)((ABL & 1) ? 0 : (tap * SL + sl)) * CT) * 2 * 64 + lane;
             const h8 bh = wp[0], bl = wp[64];
 #pragma unroll
             for (int i = 0; i < NTILE; ++i) {
-                const h8 ah = *reinterpret_cast<const h8 *>(arow[i] + sl * 32);
-                const h8 al = *reinterpret_cast<const h8 *>(arow[i] + plane_bytes + sl * 32);
+                const h8 ah = *reinterpret_cast<const h8 *>(((ABL & 2) ? arow[0] : arow[i]) + ((ABL & 2) ? 0 : sl * 32));
+                const h8 al = *reinterpret_cast<const h8 *>(((ABL & 2) ? arow[0] : arow[i]) + plane_bytes + ((ABL & 2) ? 0 : sl * 32));
                 acc[i] = mfma16(ah, bh, acc[i]);
                 acc[i] = mfma16(ah, bl, acc[i]);
                 acc[i] = mfma16(al, bh, acc[i]);
@@ -89,7 +89,7 @@ __device__ __forceinline__ void conv16(f32x16 (&acc)[NTILE], const h8 *__restric
     }
 }
 
-template <class G, int CT, int WR>
+template <class G, int CT, int WR, int ABL = 0>
 __global__ __launch_bounds__(64 * WR * CT, 2)
 void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
                           const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
@@ -147,6 +147,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
                 const _Float16 hi = (_Float16)as;
                 const _Float16 lo = (_Float16)(as - (float)hi);
                 const int idx = (wr * (MT * 32) + mt * 32 + cd_row16(v, lane)) * RS + col;
+                if ((ABL & 4) && v > 0) continue;
                 act_hi[idx] = hi;
                 act_lo[idx] = lo;
             }
@@ -199,7 +200,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[mt][v] = second ? fmaf(xres[mt][v], up, bias) : bias;
-        conv16<G, MT, 9, SL, CT>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
+        conv16<G, MT, 9, SL, CT, ABL>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
                                  abyte, vmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
         __syncthreads();
         store_act(acc, P.conv_inv[layer], second);
@@ -419,7 +420,7 @@ int resnet16_load(ResNet16Dev *n, const float *blob, size_t n_floats, hipStream_
     return 0;
 }
 
-template <int CT, int WR>
+template <int CT, int WR, int ABL = 0>
 static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
                      int max_leaves, float *out_p, float *out_v, hipStream_t s) {
     using G = Connect4;
@@ -431,12 +432,12 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, c
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward_f16<G, CT, WR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward_f16<G, CT, WR, ABL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev] = true;
     }
     const int grid = (max_leaves + TB - 1) / TB;
-    hipLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR>), dim3(grid), dim3(64 * WAVES), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
+    hipLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR, ABL>), dim3(grid), dim3(64 * WAVES), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
 }
 
 void resnet16_forward(ResNet16Dev *n, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
@@ -456,7 +457,18 @@ void resnet16_forward(ResNet16Dev *n, const u64 *mine, const u64 *theirs, const 
 #define L16(CTV, WRV) launch16<CTV, WRV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
     switch (n->CT) {
         case 1: if (wr_env == 8 || (!wr_env && max_leaves <= 768)) L16(1, 8); else L16(1, 4); break;
-        case 2: if (wr_env == 4 || (!wr_env && max_leaves <= 768)) L16(2, 4); else L16(2, 2); break;   // small batch: more waves per board
+        case 2: {
+            static const int abl = [] { const char *e = getenv("AZSP_F16_ABLATE"); return e ? atoi(e) : 0; }();
+            if (abl) {   // timing-only diagnostic builds (wrong results): 1 = no weight streaming, 2 = no LDS fragment traffic, 4 = no activation stores
+                if (abl == 1) launch16<2, 2, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+                else if (abl == 2) launch16<2, 2, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+                else if (abl == 3) launch16<2, 2, 3>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+                else launch16<2, 2, 4>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+                break;
+            }
+            if (wr_env == 4 || (!wr_env && max_leaves <= 768)) L16(2, 4); else L16(2, 2);   // small batch: more waves per board
+            break;
+        }
         case 3: L16(3, 2); break;
         default: if (wr_env == 4) L16(4, 4); else L16(4, 2); break;
     }
