@@ -6,7 +6,8 @@ from .games import BaseGame, Connect2Game, Connect4Game
 
 __all__ = ["AlphaZeroConfig", "Episode", "Sample", "BaseGame", "Connect2Game", "Connect4Game",
            "BaseModel", "ResNet", "MCTS", "Node", "EpisodeGenerator", "Engine", "generate_dataset",
-           "DeviceReplayBuffer", "save_episodes", "load_episodes"]
+           "DeviceReplayBuffer", "save_episodes", "load_episodes", "ShardedEpisodeGenerator",
+           "DistributedEpisodeGenerator"]
 
 
 def __getattr__(name):          # torch / libazsp are only imported when their classes are used
@@ -22,6 +23,9 @@ def __getattr__(name):          # torch / libazsp are only imported when their c
     if name == "Engine":
         from .engine import Engine
         return Engine
+    if name in ("ShardedEpisodeGenerator", "DistributedEpisodeGenerator"):
+        from . import sharded
+        return getattr(sharded, name)
     if name in ("generate_dataset", "DeviceReplayBuffer", "save_episodes", "load_episodes"):
         from . import replay
         return getattr(replay, name)

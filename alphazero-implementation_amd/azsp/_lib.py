@@ -20,12 +20,13 @@ ABI_VERSION = 1
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("game", C.c_int32), ("n_slots", C.c_int32), ("n_sims", C.c_int32),
                 ("device", C.c_int32), ("res_blocks", C.c_int32), ("channels", C.c_int32), ("flags", C.c_uint32),
-                ("hash_salt", C.c_uint64), ("n_groups", C.c_int32), ("reserved", C.c_int32)]
+                ("hash_salt", C.c_uint64), ("n_groups", C.c_int32), ("arena_episodes", C.c_int32)]
 
 
 class PlyResult(C.Structure):
     _fields_ = [("ply", C.c_int32), ("n_finished", C.c_int32), ("episodes_total", C.c_int64),
-                ("samples_total", C.c_int64), ("uniforms_used", C.c_int32), ("finished", C.c_int32)]
+                ("samples_total", C.c_int64), ("uniforms_used", C.c_int32), ("finished", C.c_int32),
+                ("last_counted_slot", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -57,6 +58,8 @@ SIGNATURES = {
     "azsp_search": (C.c_int, [C.c_void_p]),
     "azsp_root_counts": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "azsp_play": (C.c_int, [C.c_void_p, _P(C.c_double), _P(PlyResult)]),
+    "azsp_play_begin": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_int32)]),
+    "azsp_play_commit": (C.c_int, [C.c_void_p, C.c_int64, _P(PlyResult)]),
     "azsp_fetch_episodes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _P(C.c_int64), _P(C.c_int32), _P(C.c_int32),
                                       _P(C.c_int8), _P(C.c_double), _P(C.c_int32), C.c_int64]),
     "azsp_export_records_device": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]),

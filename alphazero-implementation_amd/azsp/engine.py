@@ -29,7 +29,7 @@ def _ptr(a: np.ndarray | None, ty):
 
 class Engine:
     def __init__(self, game, n_slots: int, n_sims: int, *, device: int = 0, res_blocks: int = 0, channels: int = 0,
-                 timing: bool = False, hash_salt: int = 0, n_groups: int = 0, f16_split: bool = False):
+                 timing: bool = False, hash_salt: int = 0, n_groups: int = 0, f16_split: bool = False, arena_episodes: int = 0):
         self.lib = L.load()
         self.game_id = game_id_of(game)
         r, c, a, mp = (C.c_int32() for _ in range(4))
@@ -40,7 +40,7 @@ class Engine:
         self.n_slots, self.n_sims = int(n_slots), int(n_sims)
         self.res_blocks, self.channels = int(res_blocks), int(channels)
         cfg = L.Config(C.sizeof(L.Config), self.game_id, self.n_slots, self.n_sims, int(device), self.res_blocks,
-                       self.channels, (L.FLAG_TIMING if timing else 0) | (L.FLAG_F16_SPLIT if f16_split else 0), int(hash_salt) & (2**64 - 1), int(n_groups), 0)
+                       self.channels, (L.FLAG_TIMING if timing else 0) | (L.FLAG_F16_SPLIT if f16_split else 0), int(hash_salt) & (2**64 - 1), int(n_groups), int(arena_episodes))
         h = C.c_void_p()
         L.check(self.lib.azsp_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -140,6 +140,21 @@ class Engine:
             raise ValueError(f"need {self.n_slots} uniforms, got {u.size}")
         res = L.PlyResult()
         self._check(self.lib.azsp_play(self._h, _ptr(u, C.c_double), C.byref(res)))
+        return res
+
+    def play_begin(self, uniforms: np.ndarray) -> int:
+        """Phase 1 of a sharded ply: sample + apply moves; returns how many games of this shard ended."""
+        u = np.ascontiguousarray(uniforms, dtype=np.float64)
+        if u.size != self.n_slots:
+            raise ValueError(f"need {self.n_slots} uniforms, got {u.size}")
+        n_done = C.c_int32(0)
+        self._check(self.lib.azsp_play_begin(self._h, _ptr(u, C.c_double), C.byref(n_done)))
+        return int(n_done.value)
+
+    def play_commit(self, allow: int) -> L.PlyResult:
+        """Phase 2: emit the first `allow` completions of this ply (slot order), restart finished slots."""
+        res = L.PlyResult()
+        self._check(self.lib.azsp_play_commit(self._h, int(allow), C.byref(res)))
         return res
 
     def fetch_episodes(self, first: int, n: int) -> dict[str, np.ndarray]:

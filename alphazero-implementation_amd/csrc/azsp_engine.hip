@@ -68,6 +68,7 @@ struct azsp_engine {
     ResNetDev *net = nullptr;
     bool net_loaded = false;
     bool searched = false;
+    bool play_open = false;       // between azsp_play_begin and azsp_play_commit
     // pinned host staging
     PlyResultDev *h_res = nullptr;
     int32_t *h_nleaf = nullptr;
@@ -249,6 +250,8 @@ static int search(azsp_engine *e, int n_act) {
     e->v.lo = 0;
     e->v.grp = 0;
     e->v.n_act = n_act;
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(AZSP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
     e->stats.plies++;
     e->rounds_host += (uint64_t)e->cfg.n_sims + 1;
     e->searched = true;
@@ -317,6 +320,8 @@ static int create_impl(azsp_engine *e) {
     HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     View &v = e->v;
     const int N = c.n_slots, A = gi.A, S = c.n_sims;
+    const int EPS = c.arena_episodes > N ? c.arena_episodes : N;
+    v.cap_eps = EPS;
     v.n_slots = v.n_act = N;
     v.lo = 0;
     v.grp = 0;
@@ -341,11 +346,11 @@ static int create_impl(azsp_engine *e) {
     DEV_ALLOC(sq, S + 2);
     v.sqrt_tab = sq;
     DEV_ALLOC(v.cur_mine, N); DEV_ALLOC(v.cur_theirs, N); DEV_ALLOC(v.cur_len, N);
-    const size_t NH = (size_t)N * gi.max_plies;
+    const size_t NH = (size_t)N * gi.max_plies, NA = (size_t)EPS * gi.max_plies;
     DEV_ALLOC(v.h_mine, NH); DEV_ALLOC(v.h_theirs, NH); DEV_ALLOC(v.h_counts, NH * LANES);
     DEV_ALLOC(v.done, N); DEV_ALLOC(v.reward, N); DEV_ALLOC(v.chosen, N); DEV_ALLOC(v.emit_off, N);
-    DEV_ALLOC(v.ep_offset, N + 1); DEV_ALLOC(v.ep_slot, N); DEV_ALLOC(v.ep_ply, N);
-    DEV_ALLOC(v.out_states, NH * gi.cells); DEV_ALLOC(v.out_policies, NH * A); DEV_ALLOC(v.out_values, NH);
+    DEV_ALLOC(v.ep_offset, EPS + 1); DEV_ALLOC(v.ep_slot, EPS); DEV_ALLOC(v.ep_ply, EPS);
+    DEV_ALLOC(v.out_states, NA * gi.cells); DEV_ALLOC(v.out_policies, NA * A); DEV_ALLOC(v.out_values, NA);
     DEV_ALLOC(v.totals, 4); DEV_ALLOC(v.counters, 8);
     DEV_ALLOC(e->d_uniforms, N); DEV_ALLOC(e->d_cells, (size_t)N * gi.cells);
     DEV_ALLOC(e->d_tmp_mine, N); DEV_ALLOC(e->d_tmp_theirs, N);
@@ -518,16 +523,36 @@ int azsp_root_counts(azsp_engine *e, int32_t *counts) {
     return sync_stream(e);
 }
 
-int azsp_play(azsp_engine *e, const double *uniforms, azsp_ply_result *out) {
-    if (!e || !uniforms || !out) return fail(AZSP_ERR_ARG, "null argument");
+int azsp_play_begin(azsp_engine *e, const double *uniforms, int32_t *n_done) {
+    if (!e || !uniforms) return fail(AZSP_ERR_ARG, "null argument");
     if (!e->searched) return fail(AZSP_ERR_STATE, "azsp_play before azsp_search");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int N = e->cfg.n_slots;
     HIP_TRY(hipMemcpyAsync(e->d_uniforms, uniforms, (size_t)N * sizeof(double), hipMemcpyHostToDevice, e->stream));
     EventPair *p = ev_begin(e, EV_PLAY, e->stream);
     launch_finish(e->cfg.game, e->v, e->d_uniforms, e->stream);
-    launch_emit(e->cfg.game, e->v, e->h_res, e->stream);
+    if (n_done) launch_count_done(e->v, e->h_nleaf, e->stream);
     ev_end(p, e->stream);
+    e->searched = false;
+    e->play_open = true;
+    if (n_done) {
+        int rc = sync_stream(e);
+        if (rc) return rc;
+        *n_done = *e->h_nleaf;
+    }
+    return 0;
+}
+
+int azsp_play_commit(azsp_engine *e, int64_t allow, azsp_ply_result *out) {
+    if (!e || !out) return fail(AZSP_ERR_ARG, "null argument");
+    if (!e->play_open) return fail(AZSP_ERR_STATE, "azsp_play_commit without azsp_play_begin");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    EventPair *p = ev_begin(e, EV_PLAY, e->stream);
+    launch_emit(e->cfg.game, e->v, e->h_res, allow < 0 ? -1ll : (long long)allow, e->stream);
+    ev_end(p, e->stream);
+    e->play_open = false;
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(AZSP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
     int rc = sync_stream(e);
     if (rc) return rc;
     out->ply = e->h_res->ply;
@@ -536,8 +561,16 @@ int azsp_play(azsp_engine *e, const double *uniforms, azsp_ply_result *out) {
     out->samples_total = e->h_res->samples_total;
     out->uniforms_used = e->h_res->uniforms_used;
     out->finished = e->h_res->finished;
-    e->searched = false;
+    out->last_counted_slot = e->h_res->last_counted_slot;
+    out->reserved = 0;
     return 0;
+}
+
+int azsp_play(azsp_engine *e, const double *uniforms, azsp_ply_result *out) {
+    if (!out) return fail(AZSP_ERR_ARG, "null argument");
+    int rc = azsp_play_begin(e, uniforms, nullptr);
+    if (rc) return rc;
+    return azsp_play_commit(e, -1, out);
 }
 
 int azsp_fetch_episodes(azsp_engine *e, int64_t first, int64_t n, int64_t *ep_offset, int32_t *ep_slot, int32_t *ep_ply,

@@ -23,6 +23,7 @@ struct View {
     int32_t grp;       // group index: selects n_leaf[grp]
     int32_t n_act;     // slots in the group: [lo, lo + n_act)
     int32_t n_slots;
+    int32_t cap_eps;   // episode capacity of the arena (>= n_slots)
     int32_t A;         // actions
     int32_t C;         // node capacity per tree (array stride)
     int32_t E;         // block capacity per tree = n_sims + 1
@@ -74,6 +75,7 @@ struct PlyResultDev {   // mirrors azsp_ply_result; written by k_emit_scan into 
     int32_t ply, n_finished;
     int64_t episodes_total, samples_total;
     int32_t uniforms_used, finished;
+    int32_t last_counted_slot, pad;
 };
 
 // launchers (azsp_tree.hip)
@@ -84,7 +86,8 @@ void launch_eval_hash(int game, const View &v, uint64_t salt, hipStream_t s);
 void launch_expand(int game, const View &v, hipStream_t s);
 void launch_leaf_cells(int game, const View &v, int8_t *dst, hipStream_t s);
 void launch_finish(int game, const View &v, const double *uniforms, hipStream_t s);
-void launch_emit(int game, const View &v, PlyResultDev *host_result, hipStream_t s);
+void launch_count_done(const View &v, int32_t *out, hipStream_t s);
+void launch_emit(int game, const View &v, PlyResultDev *host_result, long long cap, hipStream_t s);
 void launch_reset_slots(int game, const View &v, hipStream_t s);
 void launch_set_boards(int game, const View &v, const u64 *mine, const u64 *theirs, int n, hipStream_t s);
 void launch_root_stats(int game, const View &v, int32_t *counts, float *child_w, double *prior, float *root_w,

@@ -312,7 +312,24 @@ __global__ __launch_bounds__(64) void k_finish(View v, const double *uniforms) {
 }
 
 // first-N-completions bookkeeping (episode_generator.py:78-87); one workgroup, slot order
-__global__ __launch_bounds__(1024) void k_emit_scan(View v, PlyResultDev *res) {
+// number of games that ended this ply (before any cap), for the two-phase play of the sharded exact mode
+__global__ __launch_bounds__(1024) void k_count_done(View v, int32_t *out) {
+    __shared__ int s_c[1024];
+    const int t = threadIdx.x;
+    int c = 0;
+    for (int g = t; g < v.n_act; g += 1024) c += v.done[g];
+    s_c[t] = c;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (t < off) s_c[t] += s_c[t + off];
+        __syncthreads();
+    }
+    if (t == 0) *out = s_c[0];
+}
+
+// `cap` >= 0: emit at most `cap` of this ply's completions (slot order) -- the caller owns the stop rule
+// (sharded exact mode); cap < 0: the engine's own first-n_slots rule.
+__global__ __launch_bounds__(1024) void k_emit_scan(View v, PlyResultDev *res, long long cap) {
     __shared__ int s_ep[1024];
     __shared__ int s_sm[1024];
     __shared__ int s_last;
@@ -320,7 +337,8 @@ __global__ __launch_bounds__(1024) void k_emit_scan(View v, PlyResultDev *res) {
     const int per = (v.n_act + 1023) / 1024;
     const int lo = t * per, hi = min(lo + per, v.n_act);
     const long long ep0 = v.totals[0], sm0 = v.totals[1];
-    const long long remaining = (long long)v.n_slots - ep0;
+    long long remaining = cap >= 0 ? cap : (long long)v.n_slots - ep0;
+    if (remaining > (long long)v.cap_eps - ep0) remaining = (long long)v.cap_eps - ep0;   // never overrun the arena
     if (t == 0) s_last = -1;
     int ce = 0;
     for (int g = lo; g < hi; ++g) ce += v.done[g];
@@ -371,8 +389,9 @@ __global__ __launch_bounds__(1024) void k_emit_scan(View v, PlyResultDev *res) {
         res->n_finished = (int)counted;
         res->episodes_total = ep1;
         res->samples_total = sm1;
-        res->finished = ep1 >= v.n_slots;
-        res->uniforms_used = (ep1 >= v.n_slots && s_last >= 0) ? s_last + 1 : v.n_act;
+        res->finished = cap >= 0 ? 0 : ep1 >= v.n_slots;
+        res->uniforms_used = (cap < 0 && ep1 >= v.n_slots && s_last >= 0) ? s_last + 1 : v.n_act;
+        res->last_counted_slot = (total_done >= remaining && remaining > 0) ? s_last : -1;   // slot of the cap-th completion
         v.totals[0] = ep1;
         v.totals[1] = sm1;
         v.totals[2] = v.totals[2] + 1;
@@ -510,8 +529,11 @@ void launch_leaf_cells(int game, const View &v, int8_t *dst, hipStream_t s) {
 void launch_finish(int game, const View &v, const double *uniforms, hipStream_t s) {
     GAME_SWITCH(game, hipLaunchKernelGGL(k_finish<G>, dim3(groups_grid(v.n_act)), dim3(64), 0, s, v, uniforms));
 }
-void launch_emit(int game, const View &v, PlyResultDev *res, hipStream_t s) {
-    hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(1024), 0, s, v, res);
+void launch_count_done(const View &v, int32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_count_done, dim3(1), dim3(1024), 0, s, v, out);
+}
+void launch_emit(int game, const View &v, PlyResultDev *res, long long cap, hipStream_t s) {
+    hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(1024), 0, s, v, res, cap);
     GAME_SWITCH(game, hipLaunchKernelGGL(k_emit_copy<G>, dim3(groups_grid(v.n_act)), dim3(64), 0, s, v));
 }
 void launch_reset_slots(int, const View &v, hipStream_t s) {

@@ -62,7 +62,8 @@ typedef struct azsp_config {
     uint64_t hash_salt;      /* AZSP_EVAL_HASH only                                                   */
     int32_t  n_groups;       /* slot groups searched concurrently on separate HIP streams (1..8);
                                 0 = automatic.  Results do not depend on it.                          */
-    int32_t  reserved;
+    int32_t  arena_episodes; /* episode capacity of the output arena; 0 = n_slots.  The sharded exact mode
+                                (azsp_play_begin/commit) lets one shard emit more than its own n_slots.    */
 } azsp_config;
 
 /* Host evaluator: boards int8[n][cells] (canonical) -> p float32[n][n_actions], v float32[n].
@@ -78,7 +79,9 @@ typedef struct azsp_ply_result {
     int32_t uniforms_used;     /* how many of the n_slots uniforms the reference would have drawn:
                                   n_slots, or (last counted slot + 1) in the stopping ply
                                   (episode_generator.py:84-87 returns inside the slot loop)         */
-    int32_t finished;          /* 1 once episodes_total >= n_slots                                    */
+    int32_t finished;          /* 1 once episodes_total >= n_slots (always 0 when the caller passed a cap)     */
+    int32_t last_counted_slot; /* slot of the completion that exhausted the cap / the stop rule, else -1   */
+    int32_t reserved;
 } azsp_ply_result;
 
 typedef struct azsp_stats {
@@ -136,6 +139,13 @@ int  azsp_search(azsp_engine *e);                      /* :31-36  run_batch on t
 int  azsp_root_counts(azsp_engine *e, int32_t *counts);/* int32[n_slots][A] of the search just run   */
 /* :38-87  pi, sample (one uniform per slot, slot order), apply, terminal test, emit, restart.      */
 int  azsp_play(azsp_engine *e, const double *uniforms, azsp_ply_result *out);
+/* The same in two phases, for running ONE reference generator sharded over several engines/GPUs with the
+ * reference's exact global stop rule (episode_generator.py:84-87; SURVEY.md 8e "mode A"): begin = sample and
+ * apply the moves and report how many games of this shard ended; the caller combines the counts of all shards
+ * in slot order and tells each shard how many of its completions are still within the first N (allow);
+ * commit = emit exactly those (slot order) and restart the finished slots.  allow < 0 = azsp_play's rule. */
+int  azsp_play_begin(azsp_engine *e, const double *uniforms, int32_t *n_done);
+int  azsp_play_commit(azsp_engine *e, int64_t allow, azsp_ply_result *out);
 /* Copy emitted episodes [first, first+n) to host (any pointer may be NULL):
  *   ep_offset int64[n+1]  sample range of each episode, relative to the first copied sample
  *   ep_slot int32[n], ep_ply int32[n]   where/when the episode finished

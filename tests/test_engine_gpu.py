@@ -324,3 +324,81 @@ def test_device_dataset_equals_format_dataset_of_yielded_episodes(azsp):
     for _ in range(3):
         buf.extend(dev_ds)
     assert len(buf) == 2 * len(dev_ds) and buf.dataset().tensors[0].shape[0] == 2 * len(dev_ds)
+
+
+@pytest.mark.parametrize("shards,n,sims", [(2, 96, 30), (3, 100, 25), (4, 64, 40)])
+def test_sharded_exact_mode_equals_one_sequential_reference_run(azsp, shards, n, sims):
+    """SURVEY 8e mode A: ONE generator run of n slots cut over several engines (here: several engines on the
+    one GPU of the test box) with per-ply exchange of completion counts must be bit-identical -- episodes,
+    their global order, pi, z and the RNG position -- to the sequential run of the same n slots (C oracle)."""
+    seed, salt = 31 + shards, 6
+    ref = co.generate("connect4", sims, n, salt, seed=seed, trace=False)
+    gen = azsp.ShardedEpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1),
+                                       devices=[0] * shards)
+    np.random.seed(seed)
+    eps = list(gen.generate_episodes(HashStub("connect4", salt)))
+    gen.close()
+    assert float(np.random.random_sample()) == ref["next_uniform"]
+    assert len(eps) == n
+    for e, ep in enumerate(eps):
+        lo, hi = ref["ep_offset"][e], ref["ep_offset"][e + 1]
+        assert np.array_equal(np.stack([s.state for s in ep.samples]).reshape(hi - lo, -1), ref["states"][lo:hi])
+        assert np.array_equal(np.stack([s.policy for s in ep.samples]), ref["policies"][lo:hi])
+        assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()
+
+
+def _dist_worker(rank, world, port, n, sims, seed, salt, q):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "alphazero-implementation_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import azsp
+    from helpers import HashStub as Stub
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gen = azsp.DistributedEpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1),
+                                               dist=dist, device=0, coll_device=torch.device("cpu"))
+        np.random.seed(seed)                       # identical RNG on every rank
+        out = [(ply, slot, [s.state.tolist() for s in ep.samples], [s.policy.tolist() for s in ep.samples],
+                [s.value for s in ep.samples]) for ep, ply, slot in gen.generate_episodes(Stub("connect4", salt))]
+        q.put((rank, out, float(np.random.random_sample())))
+    except BaseException as exc:       # noqa: BLE001  report instead of leaving the parent waiting
+        q.put((rank, repr(exc), None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_exact_mode_two_ranks_gloo_rehearsal(azsp):
+    """DistributedEpisodeGenerator with 2 ranks (both on this box's one GPU, gloo for the tiny per-ply count
+    exchange): the union of the ranks' episodes, merged by (ply, global slot), is the sequential reference run."""
+    import socket
+    import torch.multiprocessing as mp
+    n, sims, seed, salt = 48, 20, 77, 2
+    ref = co.generate("connect4", sims, n, salt, seed=seed, trace=False)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, n, sims, seed, salt, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(after is not None for _, _, after in got), got
+    assert all(p.exitcode == 0 for p in procs)
+    assert all(after == ref["next_uniform"] for _, _, after in got)      # every rank's RNG ends at the reference position
+    merged = sorted((e for _, eps, _ in got for e in eps), key=lambda t: (t[0], t[1]))
+    assert len(merged) == n
+    for e, (ply, slot, states, pols, vals) in enumerate(merged):
+        lo, hi = ref["ep_offset"][e], ref["ep_offset"][e + 1]
+        assert ply == ref["ep_ply"][e] and slot == ref["ep_slot"][e]
+        assert np.array_equal(np.array(states).reshape(hi - lo, -1), ref["states"][lo:hi])
+        assert np.array_equal(np.array(pols), ref["policies"][lo:hi]) and vals == ref["values"][lo:hi].tolist()

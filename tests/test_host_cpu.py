@@ -122,3 +122,24 @@ def test_episode_json_wire_format_roundtrip(tmp_path):
         assert len(a) == len(b)
         for x, y in zip(a.samples, b.samples):
             assert np.array_equal(x.state, y.state) and np.array_equal(x.policy, y.policy) and x.value == y.value
+
+
+def test_shard_allowances_reproduce_the_global_first_n_rule():
+    """Brute-force check of the per-ply bookkeeping of the sharded exact mode against a flat slot scan."""
+    from azsp.sharded import shard_allowances, shard_ranges
+    rng = np.random.RandomState(0)
+    for _ in range(500):
+        g = int(rng.randint(1, 6))
+        n = int(rng.randint(g, 40))
+        ranges = shard_ranges(n, g)
+        assert ranges[0][0] == 0 and ranges[-1][1] == n and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        done = rng.rand(n) < rng.rand()
+        remaining = int(rng.randint(0, n + 3))
+        allow, stop = shard_allowances([int(done[lo:hi].sum()) for lo, hi in ranges], remaining)
+        counted = np.flatnonzero(done)[:max(remaining, 0)]
+        assert allow == [int(((counted >= lo) & (counted < hi)).sum()) for lo, hi in ranges]
+        if remaining > 0 and done.sum() >= remaining:
+            last = counted[-1]
+            assert stop == [r for r, (lo, hi) in enumerate(ranges) if lo <= last < hi][0]
+        else:
+            assert stop is None
