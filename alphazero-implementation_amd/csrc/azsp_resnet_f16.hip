@@ -66,26 +66,51 @@ template <class G, int NTILE, int TAPS, int SL, int CT, int ABL = 0>
 __device__ __forceinline__ void conv16(f32x16 (&acc)[NTILE], const h8 *__restrict__ w, const unsigned char *plane_hi,
                                        int plane_bytes, const int (&abyte)[NTILE], const uint32_t (&vmask)[NTILE],
                                        int row_bytes, int zero_byte, int lane) {
-    for (int tap = 0; tap < TAPS; ++tap) {
+    // Written as a software pipeline over the flattened (tap, slab, row tile) sequence (A fragments of the next
+    // tile and B fragments two slabs ahead are requested before the three MFMAs of the current tile).  hipcc's
+    // scheduler re-orders this freely (measured: same speed as the naive loop; pinning the order with
+    // sched_barrier makes its waits conservative: -6 % at 4096 boards, +13 % at 100) -- see DESIGN.md section 10.
+    auto arow_of = [&](int tap, int i) -> const unsigned char * {
         const int t9 = (TAPS == 9) ? tap : 4;
         const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
-        const unsigned char *arow[NTILE];
+        return plane_hi + (((vmask[i] >> t9) & 1u) ? abyte[i] + (dy * G::COLS + dx) * row_bytes : zero_byte);
+    };
+    auto wptr = [&](int q) -> const h8 * {          // q = tap * SL + slab (clamped at the end of the layer)
+        const int qq = q < TAPS * SL ? q : TAPS * SL - 1;
+        return w + ((size_t)((ABL & 1) ? 0 : qq) * CT) * 2 * 64 + lane;
+    };
+    const unsigned char *arow[NTILE], *arow_n[NTILE];
 #pragma unroll
-        for (int i = 0; i < NTILE; ++i)
-            arow[i] = plane_hi + (((vmask[i] >> t9) & 1u) ? abyte[i] + (dy * G::COLS + dx) * row_bytes : zero_byte);
+    for (int i = 0; i < NTILE; ++i) arow[i] = arow_of(0, i);
+    h8 ah_n = *reinterpret_cast<const h8 *>(arow[0]);
+    h8 al_n = *reinterpret_cast<const h8 *>(arow[0] + plane_bytes);
+    h8 bh_1 = wptr(0)[0], bl_1 = wptr(0)[64];       // slab q
+    h8 bh_2 = wptr(1)[0], bl_2 = wptr(1)[64];       // slab q + 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const int tn = tap + 1 < TAPS ? tap + 1 : tap;
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i) arow_n[i] = arow_of(tn, i);
 #pragma unroll
         for (int sl = 0; sl < SL; ++sl) {
-            const h8 *wp = w + ((size_t)((ABL & 1) ? 0 : (tap * SL + sl)) * CT) * 2 * 64 + lane;
-            const h8 bh = wp[0], bl = wp[64];
+            const h8 bh = bh_1, bl = bl_1;
+            bh_1 = bh_2; bl_1 = bl_2;
+            const h8 *wn = wptr(tap * SL + sl + 2);
+            bh_2 = wn[0]; bl_2 = wn[64];
 #pragma unroll
             for (int i = 0; i < NTILE; ++i) {
-                const h8 ah = *reinterpret_cast<const h8 *>(((ABL & 2) ? arow[0] : arow[i]) + ((ABL & 2) ? 0 : sl * 32));
-                const h8 al = *reinterpret_cast<const h8 *>(((ABL & 2) ? arow[0] : arow[i]) + plane_bytes + ((ABL & 2) ? 0 : sl * 32));
+                const h8 ah = ah_n, al = al_n;
+                const unsigned char *nx = (i + 1 < NTILE) ? arow[i + 1] + sl * 32
+                                        : (sl + 1 < SL)   ? arow[0] + (sl + 1) * 32
+                                                          : arow_n[0];
+                ah_n = *reinterpret_cast<const h8 *>(nx);
+                al_n = *reinterpret_cast<const h8 *>(nx + plane_bytes);
                 acc[i] = mfma16(ah, bh, acc[i]);
                 acc[i] = mfma16(ah, bl, acc[i]);
                 acc[i] = mfma16(al, bh, acc[i]);
             }
         }
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i) arow[i] = arow_n[i];
     }
 }
 
