@@ -80,3 +80,27 @@ def check_episode_invariants(rules, states, policies, values, sims):
     assert z_last in outcomes
     expect = [z_last if (L - 1 - k) % 2 == 0 else -z_last for k in range(L)]
     assert [int(v) for v in values] == expect
+
+
+# The reference's MCTSTests (src/alphazero_simple/tests.py:9-87) are written against an older API and error out
+# today; their intent -- Connect2, a mock evaluator with fixed priors, an ordering of root visit counts -- is
+# restated here against the list-based predict API.  (priors, value, canonical start board, sims, assertion)
+MCTS_INTENT_CASES = [
+    ([0.26, 0.24, 0.24, 0.26], 0.0001, [0, 0, 0, 0], 50,        # tests.py:10-33 centre beats the edge
+     lambda c: max(c[1], c[2]) > c[0]),
+    ([0.3, 0.7, 0.0, 0.0], 0.0001, [0, 0, 1, -1], 25,           # tests.py:35-52
+     lambda c: c[1] > c[0]),
+    ([0.51, 0.49, 0.0, 0.0], 0.0001, [0, 0, -1, 1], 25,         # tests.py:54-68 the winning move overtakes the prior
+     lambda c: c[0] < c[1]),
+    ([0.0, 0.3, 0.3, 0.3], 0.0001, [-1, 0, 0, 0], 100,          # tests.py:70-87
+     lambda c: c[1] > c[2] and c[1] > c[3]),
+]
+
+
+class FixedPriorModel:
+    def __init__(self, priors, value):
+        self.p = np.array(priors, dtype=np.float32)
+        self.v = np.float32(value)
+
+    def predict(self, boards):
+        return [self.p.copy() for _ in boards], [self.v for _ in boards]

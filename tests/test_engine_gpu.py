@@ -402,3 +402,35 @@ def test_distributed_exact_mode_two_ranks_gloo_rehearsal(azsp):
         assert ply == ref["ep_ply"][e] and slot == ref["ep_slot"][e]
         assert np.array_equal(np.array(states).reshape(hi - lo, -1), ref["states"][lo:hi])
         assert np.array_equal(np.array(pols), ref["policies"][lo:hi]) and vals == ref["values"][lo:hi].tolist()
+
+
+def test_reference_mcts_tests_intent_on_the_engine(azsp):
+    """The reference's own (stale) MCTSTests, restated: Connect2 + fixed-prior mock evaluator through the
+    MCTS facade (host-callback evaluator); visit counts equal the oracle's and satisfy the asserted orderings."""
+    from helpers import MCTS_INTENT_CASES, FixedPriorModel
+    rules = oz.C2Rules()
+    for priors, value, board, sims, check in MCTS_INTENT_CASES:
+        model = FixedPriorModel(priors, value)
+        root = azsp.MCTS(azsp.Connect2Game(), model, sims).run(np.array(board), to_play=1)
+        counts = [root.children[a].visit_count if a in root.children else 0 for a in range(4)]
+        ref = oz.run_batch(rules, model.predict, sims, [np.array(board)], [1])[0]
+        assert counts == oz.root_counts(ref, 4) and check(counts)
+        assert root.visit_count == sims and float(root.value_sum) == float(ref.w)
+
+
+@pytest.mark.parametrize("seed,salt", [(101, 11), (102, 12)])
+def test_large_randomised_differential_run(azsp, seed, salt):
+    """A longer differential run (2048 games x 150 sims, ~9 M simulations per seed) against the C oracle: any
+    rare divergence (ties, deep trees, slot restarts late in the run) would show as a mismatch."""
+    n, sims = 2048, 150
+    ref = co.generate("connect4", sims, n, salt, seed=seed, trace=False)
+    np.random.seed(seed)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    eps = list(gen.generate_episodes(HashStub("connect4", salt)))
+    assert float(np.random.random_sample()) == ref["next_uniform"]
+    flat_s = np.concatenate([np.stack([s.state for s in ep.samples]).reshape(len(ep), -1) for ep in eps])
+    flat_p = np.concatenate([np.stack([s.policy for s in ep.samples]) for ep in eps])
+    flat_v = np.array([s.value for ep in eps for s in ep.samples])
+    assert np.array_equal(flat_s, ref["states"]) and np.array_equal(flat_p, ref["policies"])
+    assert np.array_equal(flat_v, ref["values"])
+    assert [len(ep) for ep in eps] == np.diff(ref["ep_offset"][:n + 1]).tolist()

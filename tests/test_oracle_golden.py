@@ -265,3 +265,12 @@ def test_oracle_with_resnet_reproduces_reference_config1():
         first = np.array(trace[0]["counts"]) / run["sims"]
         assert np.max(np.abs(first - np.array(run["plies"][0]["counts"][0]) / run["sims"])) <= 0.08
         pytest.skip("torch-CPU outputs differ bitwise on this host; transcript compared on ply 0 only")
+
+
+def test_reference_mcts_tests_intent_holds_in_the_oracle():
+    from helpers import MCTS_INTENT_CASES, FixedPriorModel
+    rules = oz.C2Rules()
+    for priors, value, board, sims, check in MCTS_INTENT_CASES:
+        root = oz.run_batch(rules, FixedPriorModel(priors, value).predict, sims, [np.array(board)], [1])[0]
+        counts = oz.root_counts(root, 4)
+        assert sum(counts) == sims and check(counts), (priors, counts)
