@@ -526,6 +526,8 @@ int azsp_root_counts(azsp_engine *e, int32_t *counts) {
 int azsp_play_begin(azsp_engine *e, const double *uniforms, int32_t *n_done) {
     if (!e || !uniforms) return fail(AZSP_ERR_ARG, "null argument");
     if (!e->searched) return fail(AZSP_ERR_STATE, "azsp_play before azsp_search");
+    if (e->cfg.n_sims == 0)
+        return fail(AZSP_ERR_STATE, "n_sims = 0: the visit distribution is 0/0 (the reference raises in np.random.choice)");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int N = e->cfg.n_slots;
     HIP_TRY(hipMemcpyAsync(e->d_uniforms, uniforms, (size_t)N * sizeof(double), hipMemcpyHostToDevice, e->stream));
