@@ -59,8 +59,10 @@ def pmc_traffic(kernel: str):
 
 
 def cpu_baseline(sims: int, slots: int, state_dict) -> dict:
-    """oracle/az_oracle.py + oracle/resnet_ref.py (port of the reference's Python/torch-CPU path)."""
+    """The oracle's port of the reference's Python/torch-CPU path (oracle/az_oracle.py + oracle/resnet_ref.py),
+    plus, as a second figure, the plain-C tree search of oracle/az_oracle.c driving the same torch-CPU network."""
     from oracle import az_oracle as oz
+    from oracle import c_oracle as co
     from oracle.resnet_ref import ResNetRef
     cores = os.cpu_count() or 1
     threads = min(cores, 16)
@@ -70,9 +72,20 @@ def cpu_baseline(sims: int, slots: int, state_dict) -> dict:
     t0 = time.perf_counter()
     eps = list(oz.generate_episodes(oz.C4Rules(), net.predict, sims, slots))
     dt = time.perf_counter() - t0
-    return {"value": len(eps) / dt, "unit": "episodes/s", "cores": threads, "kind": "port",
-            "sample": f"{slots} concurrent games x {sims} sims, first {len(eps)} completions, {dt:.1f} s, "
-                      f"{net.boards_seen} net evals, host has {cores} logical cores"}
+    out = {"value": len(eps) / dt, "unit": "episodes/s", "cores": threads, "kind": "port",
+           "sample": f"{slots} concurrent games x {sims} sims, first {len(eps)} completions, {dt:.1f} s, "
+                     f"{net.boards_seen} net evals, host has {cores} logical cores"}
+    try:
+        net2 = ResNetRef(state_dict)
+        cb = co.make_predict_cb(net2.predict, (6, 7), 7)
+        t0 = time.perf_counter()
+        ref = co.generate("connect4", sims, slots, seed=0, predict_cb=cb, trace=False)
+        dt2 = time.perf_counter() - t0
+        out["c_tree_torch_net"] = {"value": ref["n_episodes"] / dt2, "unit": "episodes/s", "seconds": dt2,
+                                   "note": "oracle/az_oracle.c tree search + the same torch-CPU network"}
+    except Exception as exc:                # noqa: BLE001  the second figure is optional
+        out["c_tree_torch_net"] = {"error": repr(exc)}
+    return out
 
 
 def main() -> None:
