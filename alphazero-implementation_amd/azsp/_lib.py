@@ -37,6 +37,10 @@ class Stats(C.Structure):
                 ("path_nodes", C.c_uint64), ("infer_union_ms", C.c_double)]
 
 
+class SearchOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("sampling_plies", C.c_int32), ("noise_eps", C.c_double)]
+
+
 PREDICT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int8), C.c_int32, C.POINTER(C.c_float),
                          C.POINTER(C.c_float))
 
@@ -57,6 +61,8 @@ SIGNATURES = {
     "azsp_reset": (C.c_int, [C.c_void_p]),
     "azsp_search": (C.c_int, [C.c_void_p]),
     "azsp_root_counts": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "azsp_set_search_options": (C.c_int, [C.c_void_p, _P(SearchOptions)]),
+    "azsp_search_with_noise": (C.c_int, [C.c_void_p, _P(C.c_double)]),
     "azsp_play": (C.c_int, [C.c_void_p, _P(C.c_double), _P(PlyResult)]),
     "azsp_play_begin": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_int32)]),
     "azsp_play_commit": (C.c_int, [C.c_void_p, C.c_int64, _P(PlyResult)]),

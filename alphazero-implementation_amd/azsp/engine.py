@@ -129,6 +129,16 @@ class Engine:
     def search(self) -> None:
         self._check(self.lib.azsp_search(self._h))
 
+    def set_search_options(self, sampling_plies: int = -1, noise_eps: float = 0.0) -> None:
+        o = L.SearchOptions(C.sizeof(L.SearchOptions), int(sampling_plies), float(noise_eps))
+        self._check(self.lib.azsp_set_search_options(self._h, C.byref(o)))
+
+    def search_with_noise(self, noise: np.ndarray) -> None:
+        z = np.ascontiguousarray(noise, dtype=np.float64)
+        if z.shape != (self.n_slots, self.n_actions):
+            raise ValueError(f"noise must be [{self.n_slots}, {self.n_actions}]")
+        self._check(self.lib.azsp_search_with_noise(self._h, _ptr(z, C.c_double)))
+
     def root_counts(self) -> np.ndarray:
         out = np.empty((self.n_slots, self.n_actions), np.int32)
         self._check(self.lib.azsp_root_counts(self._h, _ptr(out, C.c_int32)))

@@ -20,11 +20,16 @@ from .mcts import configure_engine_for_model, default_device, engine_geometry_fo
 
 class EpisodeGenerator:
     def __init__(self, *, game, config: AlphaZeroConfig, device: int | None = None, timing: bool = False,
-                 n_groups: int = 0, f16_split: bool = False):
+                 n_groups: int = 0, f16_split: bool = False, sampling_plies: int | None = None,
+                 dirichlet_alpha: float | None = None, dirichlet_eps: float = 0.25):
         self.game = game
         self.config = config
         self.device = device
         self.timing = timing
+        # search options beyond the reference (None/off = reference behaviour): arg-max moves after
+        # `sampling_plies` plies; gamma(alpha) root noise mixed in with weight `dirichlet_eps`, drawn per ply from
+        # the global numpy RNG BEFORE the ply's uniforms (n_slots x n_actions values)
+        self.sampling_plies, self.dirichlet_alpha, self.dirichlet_eps = sampling_plies, dirichlet_alpha, dirichlet_eps
         self.f16_split = f16_split    # device ResNet on the fp16 matrix pipe with split operands (fp32-class accuracy)
         self.n_groups = n_groups      # concurrent slot groups (HIP streams); 0 = automatic; never changes results
         self._engine: Engine | None = None
@@ -50,8 +55,17 @@ class EpisodeGenerator:
         n = self.config.num_episodes
         shape = eng.board_shape
         eng.reset()
+        eng.set_search_options(-1 if self.sampling_plies is None else self.sampling_plies,
+                               self.dirichlet_eps if self.dirichlet_alpha else 0.0)
+
+        def search():
+            if self.dirichlet_alpha:
+                eng.search_with_noise(np.random.gamma(self.dirichlet_alpha, 1.0, (n, eng.n_actions)))
+            else:
+                eng.search()
+
         emitted = 0
-        eng.search()
+        search()
         while True:
             rng_state = np.random.get_state()
             res = eng.play(np.random.random_sample(n))
@@ -61,7 +75,7 @@ class EpisodeGenerator:
                 np.random.set_state(rng_state)
                 np.random.random_sample(res.uniforms_used)
             if not res.finished:
-                eng.search()        # enqueue the next ply's search now: it runs on the GPU while the
+                search()            # enqueue the next ply's search now: it runs on the GPU while the
                                     # host copies and materialises the episodes that just finished
             if res.n_finished:
                 out = eng.fetch_episodes(emitted, res.n_finished)

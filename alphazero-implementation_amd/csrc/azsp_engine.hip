@@ -79,6 +79,7 @@ struct azsp_engine {
     int32_t *d_st_counts = nullptr, *d_st_rn = nullptr;     // root statistics staging
     float *d_st_w = nullptr, *d_st_rw = nullptr;
     double *d_st_prior = nullptr;
+    double *d_noise = nullptr;        // root exploration noise staging
     std::vector<int8_t> h_cells;
     std::vector<float> h_p, h_v, h_p8;
     std::vector<u64> h_mine, h_theirs;
@@ -322,6 +323,10 @@ static int create_impl(azsp_engine *e) {
     const int N = c.n_slots, A = gi.A, S = c.n_sims;
     const int EPS = c.arena_episodes > N ? c.arena_episodes : N;
     v.cap_eps = EPS;
+    v.root_noise = nullptr;
+    v.noise_eps = 0.0;
+    v.noise_keep = 1.0;
+    v.sampling_plies = -1;
     v.n_slots = v.n_act = N;
     v.lo = 0;
     v.grp = 0;
@@ -356,6 +361,7 @@ static int create_impl(azsp_engine *e) {
     DEV_ALLOC(e->d_tmp_mine, N); DEV_ALLOC(e->d_tmp_theirs, N);
     DEV_ALLOC(e->d_st_counts, (size_t)N * A); DEV_ALLOC(e->d_st_w, (size_t)N * A); DEV_ALLOC(e->d_st_prior, (size_t)N * A);
     DEV_ALLOC(e->d_st_rw, N); DEV_ALLOC(e->d_st_rn, N);
+    DEV_ALLOC(e->d_noise, (size_t)N * A);
 
     std::vector<double> tab(S + 2);
     for (int i = 0; i < S + 2; ++i) tab[i] = sqrt((double)i);     // host libm == Python math.sqrt
@@ -510,6 +516,27 @@ int azsp_search(azsp_engine *e) {
     if (!e) return fail(AZSP_ERR_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->cfg.device));
     return search(e, e->cfg.n_slots);
+}
+
+int azsp_set_search_options(azsp_engine *e, const azsp_search_options *o) {
+    if (!e || !o) return fail(AZSP_ERR_ARG, "null argument");
+    if (o->struct_size != sizeof(azsp_search_options)) return fail(AZSP_ERR_ARG, "azsp_search_options.struct_size mismatch");
+    if (o->noise_eps < 0.0 || o->noise_eps > 1.0) return fail(AZSP_ERR_ARG, "noise_eps out of [0,1]");
+    e->v.sampling_plies = o->sampling_plies;
+    e->v.noise_eps = o->noise_eps;
+    e->v.noise_keep = 1.0 - o->noise_eps;
+    return 0;
+}
+
+int azsp_search_with_noise(azsp_engine *e, const double *noise) {
+    if (!e || !noise) return fail(AZSP_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipMemcpyAsync(e->d_noise, noise, (size_t)e->cfg.n_slots * e->gi.A * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));            // the caller's buffer may be pageable
+    e->v.root_noise = e->d_noise;
+    int rc = search(e, e->cfg.n_slots);
+    e->v.root_noise = nullptr;
+    return rc;
 }
 
 int azsp_root_counts(azsp_engine *e, int32_t *counts) {

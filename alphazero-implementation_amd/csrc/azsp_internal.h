@@ -51,6 +51,10 @@ struct View {
     float   *eval_p;        // [n_slots][PSTRIDE] evaluator output, at offset lo, indexed by compacted leaf
     float   *eval_v;        // [n_slots]
     const double *sqrt_tab; // [n_sims + 2] host-computed sqrt(i): bit-identical to math.sqrt
+    // search options beyond the reference (all off by default)
+    const double *root_noise;   // [n_slots][A] or nullptr
+    double  noise_eps, noise_keep;   // eps and (1 - eps), both computed on the host
+    int32_t sampling_plies;     // < 0: always sample (reference behaviour)
     // live games
     u64     *cur_mine, *cur_theirs;     // [n_slots] canonical position (side to move = mine)
     int32_t *cur_len;                   // [n_slots] plies played in the current game

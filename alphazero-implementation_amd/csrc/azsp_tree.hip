@@ -220,13 +220,18 @@ __global__ __launch_bounds__(64) void k_expand(View v) {
     const int node = v.leaf_node[g];
     const int e = v.n_blk[g];                       // read by all 8 lanes before lane 0 bumps it
     const int fc = 1 + e * A;
+    const int L = v.path_len[g];
+    double prior = pr;
+    // optional root exploration noise (off by default; not in the reference's search, listed in its
+    // src/deepmind_alphazero_pseudocode.py:285-290): prior*(1-eps) + noise*eps on the existing root children
+    if (L == 0 && v.root_noise != nullptr && lane < A && pr != 0.0)
+        prior = pr * v.noise_keep + v.root_noise[(size_t)g * A + lane] * v.noise_eps;
     if (lane < A) {                                 // Node.expand :80-90
         v.cnt[base + fc + lane] = 0;
         v.wsum[base + fc + lane] = 0.0f;
-        v.prior[base + fc + lane] = pr;
+        v.prior[base + fc + lane] = prior;
         v.kids[base + fc + lane] = 0;
     }
-    const int L = v.path_len[g];
     const float val = v.eval_v[j];
     for (int k = lane; k < L; k += LANES) {         // backpropagate :214-223
         const int nd = v.path[(size_t)g * v.D + (L - 1 - k)];
@@ -297,6 +302,15 @@ __global__ __launch_bounds__(64) void k_finish(View v, const double *uniforms) {
             if (act < 0 && !(cdf[a] / last <= u)) act = a;                  // searchsorted(side='right')
         }
     if (act < 0) act = last_ex;
+    // optional: after `sampling_plies` plies of a game the move is the arg-max of the visit counts
+    // (Node.select_action(temperature=0), :49-50: first maximum in child order); off (< 0) by default
+    if (v.sampling_plies >= 0 && len >= v.sampling_plies) {
+        int best = -1, bc = -1;
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+            if (exs[a] && cs[a] > bc) { bc = cs[a]; best = a; }
+        act = best;
+    }
 
     u64 nm, nt;
     G::play(mine, theirs, act, nm, nt);             // episode_generator.py:55-58

@@ -137,6 +137,16 @@ int  azsp_run_batch(azsp_engine *e, const int8_t *boards, int32_t n, int32_t *co
 int  azsp_reset(azsp_engine *e);                       /* :25-29  fresh games in every slot          */
 int  azsp_search(azsp_engine *e);                      /* :31-36  run_batch on the slots' boards     */
 int  azsp_root_counts(azsp_engine *e, int32_t *counts);/* int32[n_slots][A] of the search just run   */
+/* Search options the reference does NOT have (its generator fixes temperature = 1 and uses no noise,
+ * episode_generator.py:54; they are listed in its src/deepmind_alphazero_pseudocode.py:233-290).  All off by
+ * default, so the default behaviour is the reference's.
+ *   sampling_plies >= 0: after that many plies of a game the move is arg-max of the visit counts
+ *                        (Node.select_action(temperature=0), monte_carlo_tree_search.py:49-50); < 0 = always sample
+ *   noise_eps > 0      : azsp_search_with_noise mixes caller-drawn noise into the root priors,
+ *                        prior*(1-eps) + noise*eps on existing children (noise double[n_slots][A]) */
+typedef struct azsp_search_options { uint32_t struct_size; int32_t sampling_plies; double noise_eps; } azsp_search_options;
+int  azsp_set_search_options(azsp_engine *e, const azsp_search_options *opts);
+int  azsp_search_with_noise(azsp_engine *e, const double *noise);
 /* :38-87  pi, sample (one uniform per slot, slot order), apply, terminal test, emit, restart.      */
 int  azsp_play(azsp_engine *e, const double *uniforms, azsp_ply_result *out);
 /* The same in two phases, for running ONE reference generator sharded over several engines/GPUs with the

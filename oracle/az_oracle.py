@@ -299,13 +299,19 @@ def masked_priors(p32, valid):                     # :119-121 and :165-167
     return pr
 
 
-def run_batch(rules, predict: Callable, sims: int, states, to_plays) -> list[ONode]:
-    """monte_carlo_tree_search.py:111-171."""
+def run_batch(rules, predict: Callable, sims: int, states, to_plays, root_noise=None, noise_eps: float = 0.0) -> list[ONode]:
+    """monte_carlo_tree_search.py:111-171.  `root_noise` (array [n][A]) / `noise_eps` are an EXTENSION beyond the
+    reference (off by default): root priors become prior*(1-eps) + noise*eps on existing children, the scheme of
+    the reference's src/deepmind_alphazero_pseudocode.py:285-290."""
     roots = []
     p_batch, _ = predict(states)                                   # :114 root values discarded
-    for st, tp, p in zip(states, to_plays, p_batch):
+    for i, (st, tp, p) in enumerate(zip(states, to_plays, p_batch)):
         root = ONode(0, tp)
-        root.grow(st, tp, masked_priors(p, rules.valid_moves(st)))  # :116-123
+        pr = masked_priors(p, rules.valid_moves(st))
+        if root_noise is not None:
+            keep = 1.0 - noise_eps
+            pr = np.array([x * keep + root_noise[i][a] * noise_eps if x != 0 else 0.0 for a, x in enumerate(pr)])
+        root.grow(st, tp, pr)                                       # :116-123
         roots.append(root)
 
     for _ in range(sims):                                           # :125
@@ -342,10 +348,16 @@ def root_counts(root: ONode, n_actions: int) -> list[int]:
 # Lock-step episode generation  (episode_generator.py:23-87)
 # --------------------------------------------------------------------------------------------
 def generate_episodes(rules, predict: Callable, sims: int, n_slots: int, rng=np.random,
-                      trace: list | None = None):
+                      trace: list | None = None, sampling_plies: int | None = None,
+                      dirichlet_alpha: float | None = None, dirichlet_eps: float = 0.25):
     """Yields episodes in the reference's (ply, slot) order; each episode is a list of
     (canonical_state int64, policy float64[A], value int).  ``trace`` (optional) receives one
-    dict per (ply, slot) with the root visit counts and the chosen action."""
+    dict per (ply, slot) with the root visit counts and the chosen action.
+
+    EXTENSIONS beyond the reference (None = reference behaviour; they define what the engine's options must do):
+    `sampling_plies`: from that ply of a game on the move is select_action(temperature=0) (mcts:49-50); the
+    slot's uniform is still drawn so the stream stays aligned.  `dirichlet_alpha`: per ply, before the search,
+    rng.gamma(alpha, 1, (n_slots, A)) is drawn and mixed into the root priors with weight `dirichlet_eps`."""
     A = rules.action_size
     states = [rules.init_board() for _ in range(n_slots)]            # :25
     players = [1] * n_slots                                          # :26
@@ -354,13 +366,18 @@ def generate_episodes(rules, predict: Callable, sims: int, n_slots: int, rng=np.
     ply = 0
     while True:                                                      # :30
         canon = [rules.canonical(s, p) for s, p in zip(states, players)]   # :31-34
-        roots = run_batch(rules, predict, sims, canon, players)      # :36
+        noise = rng.gamma(dirichlet_alpha, 1.0, (n_slots, A)) if dirichlet_alpha else None
+        roots = run_batch(rules, predict, sims, canon, players, noise, dirichlet_eps if dirichlet_alpha else 0.0)   # :36
         for i in range(n_slots):                                     # :38-44 slot order = RNG order
             root = roots[i]
             counts = root_counts(root, A)
             pi = counts / np.sum(counts)                             # :45-48  int/int64 -> float64
             hist[i].append((canon[i], players[i], pi))               # :50-52
-            act = root.pick_action(1, rng)                           # :54
+            if sampling_plies is not None and len(hist[i]) - 1 >= sampling_plies:
+                rng.random_sample()                                  # stream alignment (extension)
+                act = root.pick_action(0, rng)
+            else:
+                act = root.pick_action(1, rng)                       # :54
             states[i], players[i] = rules.next_state(states[i], players[i], act)   # :55-58
             rew = rules.reward(states[i], players[i])                # :59
             if trace is not None:

@@ -434,3 +434,25 @@ def test_large_randomised_differential_run(azsp, seed, salt):
     assert np.array_equal(flat_s, ref["states"]) and np.array_equal(flat_p, ref["policies"])
     assert np.array_equal(flat_v, ref["values"])
     assert [len(ep) for ep in eps] == np.diff(ref["ep_offset"][:n + 1]).tolist()
+
+
+@pytest.mark.parametrize("opts", [{"sampling_plies": 6}, {"dirichlet_alpha": 0.8, "dirichlet_eps": 0.25},
+                                  {"sampling_plies": 0}, {"sampling_plies": 4, "dirichlet_alpha": 0.3, "dirichlet_eps": 0.4}])
+def test_search_options_beyond_the_reference(azsp, opts):
+    """Temperature cut-off and root noise do not exist in the reference's generator, so the
+    reference cannot pin them: they are pinned against the oracle's documented extension, bit for bit, and
+    are off by default (every other test runs the reference's behaviour)."""
+    n, sims, seed, salt = 12, 40, 9, 3
+    rules = oz.C4Rules()
+    np.random.seed(seed)
+    ref = list(oz.generate_episodes(rules, oz.HashModel(rules, salt).predict, sims, n, **opts))
+    after = float(np.random.random_sample())
+    np.random.seed(seed)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), **opts)
+    eps = list(gen.generate_episodes(HashStub("connect4", salt)))
+    assert float(np.random.random_sample()) == after
+    assert len(eps) == len(ref) == n
+    for ep, r in zip(eps, ref):
+        assert [s.state.tolist() for s in ep.samples] == [np.asarray(s).tolist() for s, _, _ in r]
+        assert [s.policy.tolist() for s in ep.samples] == [np.asarray(p).tolist() for _, p, _ in r]
+        assert [s.value for s in ep.samples] == [int(z) for _, _, z in r]
