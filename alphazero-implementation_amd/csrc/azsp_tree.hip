@@ -66,30 +66,38 @@ __global__ __launch_bounds__(64) void k_select(View v) {
     const size_t base = (size_t)g * v.C;
     int *my_path = s_path + grp * v.D;
 
+    // One dependent round trip per tree level: the lanes fetch N, W, P AND the first-child index of their
+    // child together; the chosen child's first-child index then comes from a shuffle, and N_parent is not
+    // loaded but rebuilt from the children (an expanded node is visited once at expansion and afterwards
+    // only on the way to one of its children: N = 1 + sum N_child; the root is never counted at expansion).
     int node = 0, depth = 0, parent_fc = 0, action = 0;
+    int fc = live ? v.kids[base] : 0;
     bool walking = live;
     while (true) {
-        int fc = walking ? v.kids[base + node] : 0;
         walking = walking && fc != 0;               // Node.expanded() :35-36
         if (!__any(walking)) break;
+        const bool in = walking && lane < A;
+        const int child = fc + lane;
+        const double p = in ? v.prior[base + child] : 0.0;
+        const int n = in ? v.cnt[base + child] : 0;
+        const float w = in ? v.wsum[base + child] : 0.0f;
+        const int kc = in ? v.kids[base + child] : 0;
+        int np_ = n;
+#pragma unroll
+        for (int m = 1; m < LANES; m <<= 1) np_ += __shfl_xor(np_, m, LANES);
+        np_ += node != 0;
         double score = -INFINITY;
-        if (walking && lane < A) {
-            const int child = fc + lane;
-            const double p = v.prior[base + child];
-            if (p != 0.0) {                         // a child exists only where prob != 0  (:87)
-                const int n = v.cnt[base + child];
-                const int np_ = v.cnt[base + node];
-                // ucb_score :11-22.  (prior * sqrt(N_parent)) / (n + 1) in float64;
-                // -(W / n) in float32 (numpy 2.x), promoted for the sum.
-                const double u = (p * v.sqrt_tab[np_]) / (double)(n + 1);
-                double q = 0.0;
-                if (n > 0) {
-                    const float qf = v.wsum[base + child] / (float)n;
-                    q = (double)(-qf);
-                }
-                score = q + u;
-                if (!(score == score)) score = -INFINITY;   // NaN is never '>' the running best
+        if (in && p != 0.0) {                       // a child exists only where prob != 0  (:87)
+            // ucb_score :11-22.  (prior * sqrt(N_parent)) / (n + 1) in float64;
+            // -(W / n) in float32 (numpy 2.x), promoted for the sum.
+            const double u = (p * v.sqrt_tab[np_]) / (double)(n + 1);
+            double q = 0.0;
+            if (n > 0) {
+                const float qf = w / (float)n;
+                q = (double)(-qf);
             }
+            score = q + u;
+            if (!(score == score)) score = -INFINITY;   // NaN is never '>' the running best
         }
         // argmax, strict '>' in ascending action order == maximum score, lowest action on ties
         int best = lane;
@@ -99,11 +107,13 @@ __global__ __launch_bounds__(64) void k_select(View v) {
             const int bo = __shfl_xor(best, m, LANES);
             if (so > score || (so == score && bo < best)) { score = so; best = bo; }
         }
+        const int next_fc = __shfl(kc, best, LANES);
         if (walking) {
             if (lane == 0) my_path[depth] = node;
             parent_fc = fc;
             action = best;
             node = fc + best;
+            fc = next_fc;
             ++depth;
         }
     }
