@@ -74,10 +74,10 @@ __device__ __forceinline__ void load_w(const float *p, float (&w)[NT]) {
 //   wl   : permuted weights [tap][S][64][NTW]
 //   ridx : per row tile, float index of this lane's row (+ lane>>5) in `act`
 //   vmask: per row tile, 9-bit tap validity
-template <int NTW, int KB>
+template <int NTW, int KB, int WST>
 __device__ __forceinline__ void load_wblock(const float *p, float (&w)[KB][NTW]) {
 #pragma unroll
-    for (int i = 0; i < KB; ++i) load_w<NTW>(p + (size_t)i * 64 * NTW, w[i]);
+    for (int i = 0; i < KB; ++i) load_w<NTW>(p + (size_t)i * 64 * WST, w[i]);
 }
 
 template <int MT, int NTW, int KB>
@@ -96,7 +96,7 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[MT][NTW], const float *
     }
 }
 
-template <class G, int MT, int NTW, int TAPS, int S, int PF>
+template <class G, int MT, int NTW, int TAPS, int S, int PF, int WST = NTW>
 __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *__restrict__ wl, const float *act,
                                           const int (&ridx)[MT], const uint32_t (&vmask)[MT], int stride, int zero_idx,
                                           int lane) {
@@ -109,11 +109,11 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
                 arow[mt] = act + (((vmask[mt] >> t9) & 1u) ? ridx[mt] + (dy * G::COLS + dx) * stride : zero_idx);
-            const float *wt = wl + ((size_t)tap * S * 64 + lane) * NTW;
+            const float *wt = wl + ((size_t)tap * S * 64 + lane) * WST;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 float w[NTW];
-                load_w<NTW>(wt + (size_t)s * 64 * NTW, w);
+                load_w<NTW>(wt + (size_t)s * 64 * WST, w);
                 float a[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) a[mt] = arow[mt][2 * s];
@@ -132,10 +132,10 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
     // of the layer is prefetched too (the blob is padded accordingly) and simply not used.
     constexpr int KB = 8, NB = S / KB;
     static_assert(S % (2 * KB) == 0, "k-steps per tap must be a multiple of 16");
-    const float *wp = wl + (size_t)lane * NTW;
-    constexpr size_t BLK = (size_t)KB * 64 * NTW;
+    const float *wp = wl + (size_t)lane * WST;
+    constexpr size_t BLK = (size_t)KB * 64 * WST;
     float wA[KB][NTW], wB[KB][NTW];
-    load_wblock<NTW, KB>(wp, wA);
+    load_wblock<NTW, KB, WST>(wp, wA);
     for (int tap = 0; tap < TAPS; ++tap) {
         const int t9 = (TAPS == 9) ? tap : 4;
         const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
@@ -145,9 +145,9 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
             arow[mt] = act + (((vmask[mt] >> t9) & 1u) ? ridx[mt] + (dy * G::COLS + dx) * stride : zero_idx);
 #pragma unroll
         for (int b = 0; b < NB; b += 2) {
-            load_wblock<NTW, KB>(wp + BLK, wB);
+            load_wblock<NTW, KB, WST>(wp + BLK, wB);
             mfma_block<MT, NTW, KB>(acc, arow, b * KB, wA);
-            load_wblock<NTW, KB>(wp + 2 * BLK, wA);
+            load_wblock<NTW, KB, WST>(wp + 2 * BLK, wA);
             mfma_block<MT, NTW, KB>(acc, arow, (b + 1) * KB, wB);
             wp += 2 * BLK;
         }
@@ -158,8 +158,8 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
 //   row = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5),  col = l & 31
 __device__ __forceinline__ int cd_row(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
 
-template <class G, int NT, int MT, int PF>
-__global__ __launch_bounds__(256, (MT == 1 && NT <= 2 ? 3 : 2)) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
+template <class G, int NT, int MT, int PF, int CW = 1>
+__global__ __launch_bounds__(256 * CW, (CW == 1 && MT == 1 && NT <= 2 ? 3 : 2)) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
                                                          const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
                                                          float *__restrict__ out_p, float *__restrict__ out_v) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
@@ -167,6 +167,8 @@ __global__ __launch_bounds__(256, (MT == 1 && NT <= 2 ? 3 : 2)) void k_resnet_fo
     constexpr int WROWS = 32 * MT;                 // rows per wave
     constexpr int TB = WG_ROWS / CELLS;            // boards per workgroup
     constexpr int CP = 32 * NT, S = CP / 2, STRIDE = CP + 1;
+    constexpr int NTW = NT / CW;                   // column tiles per wave: CW waves share a row group
+    static_assert(NT % CW == 0, "column tiles must divide over the column waves");
     constexpr int ZERO_IDX = WG_ROWS * STRIDE;
     extern __shared__ float smem[];
     float *act = smem;                             // [WG_ROWS + 1][STRIDE]
@@ -176,9 +178,11 @@ __global__ __launch_bounds__(256, (MT == 1 && NT <= 2 ? 3 : 2)) void k_resnet_fo
     const int n_leaf = *n_leaf_p;
     const int board0 = blockIdx.x * TB;
     if (board0 >= n_leaf) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = (tid >> 6) / CW, wc = (tid >> 6) % CW;    // row group, column group
+    const int col0 = wc * NTW * 32;
 
-    for (int i = tid; i < STRIDE; i += 256) act[ZERO_IDX + i] = 0.0f;
+    for (int i = tid; i < STRIDE; i += 256 * CW) act[ZERO_IDX + i] = 0.0f;
 
     // ---- per-lane row geometry -------------------------------------------------------------------
     int ridx[MT];
@@ -210,14 +214,14 @@ __global__ __launch_bounds__(256, (MT == 1 && NT <= 2 ? 3 : 2)) void k_resnet_fo
         }
     }
 
-    f32x16 acc[MT][NT], xres[MT][NT];
+    f32x16 acc[MT][NTW], xres[MT][NTW];
 
     // ---- stem: conv3x3(3 -> C) + BN + ReLU, A fragments generated from the bitboards ---------------
     // (_states_to_tensor resnet.py:115-128: planes [empty, mine(+1), theirs(-1)]; input_conv :44-48)
     {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float bias = P.stem_b[nt * 32 + (lane & 31)];
+        for (int nt = 0; nt < NTW; ++nt) {
+            const float bias = P.stem_b[col0 + nt * 32 + (lane & 31)];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -226,8 +230,8 @@ __global__ __launch_bounds__(256, (MT == 1 && NT <= 2 ? 3 : 2)) void k_resnet_fo
         for (int s = 0; s < 14; ++s) {
             const int kk = 2 * s + half;               // K index = tap*3 + plane, 27 real + 1 zero
             const int tap = kk / 3, plane = kk % 3;
-            float w[NT];
-            load_w<NT>(P.stem_w + ((size_t)s * 64 + lane) * NT, w);
+            float w[NTW];
+            load_w<NTW>(P.stem_w + ((size_t)s * 64 + lane) * NT + wc * NTW, w);
             float a[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -244,18 +248,18 @@ __global__ __launch_bounds__(256, (MT == 1 && NT <= 2 ? 3 : 2)) void k_resnet_fo
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NTW; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], w[nt], acc[mt][nt], 0, 0, 0);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const float o = fmaxf(acc[mt][nt][v], 0.0f);
                     xres[mt][nt][v] = o;
-                    act[(wave * WROWS + mt * 32 + cd_row(v, lane)) * STRIDE + nt * 32 + (lane & 31)] = o;
+                    act[(wave * WROWS + mt * 32 + cd_row(v, lane)) * STRIDE + col0 + nt * 32 + (lane & 31)] = o;
                 }
     }
     __syncthreads();
@@ -266,24 +270,24 @@ __global__ __launch_bounds__(256, (MT == 1 && NT <= 2 ? 3 : 2)) void k_resnet_fo
         const float *wl = P.conv_w + (size_t)layer * P.conv_w_stride;
         const float *bl = P.conv_b + (size_t)layer * P.conv_b_stride;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float bias = bl[nt * 32 + (lane & 31)];
+        for (int nt = 0; nt < NTW; ++nt) {
+            const float bias = bl[col0 + nt * 32 + (lane & 31)];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[mt][nt][v] = second ? xres[mt][nt][v] + bias : bias;   // x += residual
         }
-        conv_mfma<G, MT, NT, 9, S, PF>(acc, wl, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
+        conv_mfma<G, MT, NTW, 9, S, PF, NT>(acc, wl + wc * NTW, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
         __syncthreads();                               // every wave is done reading the layer input
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const float o = fmaxf(acc[mt][nt][v], 0.0f);
                     if (second) xres[mt][nt][v] = o;
-                    act[(wave * WROWS + mt * 32 + cd_row(v, lane)) * STRIDE + nt * 32 + (lane & 31)] = o;
+                    act[(wave * WROWS + mt * 32 + cd_row(v, lane)) * STRIDE + col0 + nt * 32 + (lane & 31)] = o;
                 }
         __syncthreads();
     }
@@ -297,7 +301,8 @@ __global__ __launch_bounds__(256, (MT == 1 && NT <= 2 ? 3 : 2)) void k_resnet_fo
 #pragma unroll
             for (int v = 0; v < 16; ++v) accp[mt][0][v] = bp;
     }
-    conv_mfma<G, MT, 1, 1, S, PF>(accp, P.pol_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
+    if (wc == 0)      // one 32-channel tile: the first column wave of each row group computes it
+        conv_mfma<G, MT, 1, 1, S, PF>(accp, P.pol_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
     // The value conv has 3 output channels: on the matrix pipe it would be padded to a 32-wide tile
     // (+5.8 % MFMA time for 0.6 % of the FLOPs), so it runs on the vector ALU instead -- one thread per
     // board cell, weights wave-uniform (scalar loads), activations read conflict-free from LDS --
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(256, (MT == 1 && NT <= 2 ? 3 : 2)) void k_resnet_fo
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int row = wave * WROWS + mt * 32 + cd_row(v, lane);
-            act[row * STRIDE + (lane & 31)] = fmaxf(accp[mt][0][v], 0.0f);
+            if (wc == 0) act[row * STRIDE + (lane & 31)] = fmaxf(accp[mt][0][v], 0.0f);
         }
     if (tid < TB * CELLS) {
         hval[tid * 4 + 0] = fmaxf(hv0, 0.0f);
@@ -529,7 +534,7 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
     return 0;
 }
 
-template <class G, int NT, int MT, int PF>
+template <class G, int NT, int MT, int PF, int CW = 1>
 static void launch_forward(const NetParams &P, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot,
                            const int32_t *n_leaf, int max_leaves, float *out_p, float *out_v, hipStream_t s) {
     constexpr int WG_ROWS = 128 * MT;
@@ -540,12 +545,12 @@ static void launch_forward(const NetParams &P, const u64 *mine, const u64 *their
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT, MT, PF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT, MT, PF, CW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev] = true;
     }
     const int grid = (max_leaves + TB - 1) / TB;
-    hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF>), dim3(grid), dim3(256), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
+    hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW>), dim3(grid), dim3(256 * CW), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
 }
 
 void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
@@ -577,6 +582,11 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
     const bool small = max_leaves <= 768;
     if (n->g.NT == 1) { if (mt == 1) { if (pf == 0) FWD(1, 1, 0); else FWD(1, 1, 1); } else FWD(1, 2, 0); }
     else if (n->g.NT == 2) {
+        static const int cw_env = [] { const char *e = getenv("AZSP_RESNET_CW"); return e ? atoi(e) : 0; }();
+        // AZSP_RESNET_CW=2 also splits the channels over two waves (8 waves per 3 boards).  Measured: no gain --
+        // 0.201 vs 0.189 ms per launch at 100 boards -- the single-workgroup latency floor is set by barriers,
+        // epilogues and the weight stream, not by the MFMA chain; kept as a knob, off by default.
+        if (mt == 1 && cw_env == 2) { launch_forward<Connect4, 2, 1, 1, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }
         if (mt == 1) { if (pf == 0 || (pf < 0 && !small)) FWD(2, 1, 0); else FWD(2, 1, 1); }
         else { if (pf == 1) FWD(2, 2, 1); else FWD(2, 2, 0); }
     }

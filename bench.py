@@ -117,7 +117,7 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("AZSP_BENCH_FORCE_DIST") == "1":   # the latter: 1-rank rehearsal of the RCCL calls
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -147,7 +147,7 @@ def main() -> None:
         def step(seed: int):
             np.random.seed(seed)               # independent replica per rank (SURVEY 8e mode B)
             eps = list(gen.generate_episodes(net))
-            gathered = all_gather_records(gen, dist, world, coll_dev) if world > 1 else None
+            gathered = all_gather_records(gen, dist, world, coll_dev) if dist is not None else None
             return len(eps), sum(len(e) for e in eps), gathered
 
         for w in range(args.warmup):
