@@ -52,6 +52,7 @@ SIGNATURES = {
     "azsp_destroy": (None, [C.c_void_p]),
     "azsp_last_error": (C.c_char_p, []),
     "azsp_game_info": (C.c_int, [C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
+    "azsp_game_rules": (C.c_int, [C.c_int32, _P(C.c_int8), C.c_int32, _P(C.c_int8), _P(C.c_int32), _P(C.c_int32)]),
     "azsp_load_resnet": (C.c_int, [C.c_void_p, _P(C.c_float), C.c_size_t]),
     "azsp_resnet_blob_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "azsp_set_evaluator": (C.c_int, [C.c_void_p, C.c_int32, PREDICT_FN, C.c_void_p]),

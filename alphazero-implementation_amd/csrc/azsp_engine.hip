@@ -259,6 +259,19 @@ static int search(azsp_engine *e, int n_act) {
     return 0;
 }
 
+template <class G>
+static void rules_eval(const int8_t *cells, int32_t action, int8_t *next_cells, int32_t *legal_mask, int32_t *terminal) {
+    u64 m, t, nm, nt;
+    cells_to_bits<G>(cells, m, t);
+    if (legal_mask) *legal_mask = (int32_t)G::legal_mask(m, t);
+    if (terminal) *terminal = G::terminal(m, t);
+    if (next_cells) {
+        if (action < 0 || action >= G::A) { memcpy(next_cells, cells, G::CELLS); return; }
+        G::play(m, t, action, nm, nt);
+        bits_to_cells<G>(nm, nt, next_cells);
+    }
+}
+
 // =================================================================================================
 // C ABI
 // =================================================================================================
@@ -276,6 +289,16 @@ int azsp_game_info(int32_t game, int32_t *rows, int32_t *cols, int32_t *n_action
     if (n_actions) *n_actions = gi.A;
     if (max_plies) *max_plies = gi.max_plies;
     return 0;
+}
+
+int azsp_game_rules(int32_t game, const int8_t *cells, int32_t action, int8_t *next_cells, int32_t *legal_mask,
+                    int32_t *terminal) {
+    if (!cells) return fail(AZSP_ERR_ARG, "null board");
+    switch (game) {
+        case AZSP_GAME_CONNECT4: rules_eval<Connect4>(cells, action, next_cells, legal_mask, terminal); return 0;
+        case AZSP_GAME_CONNECT2: rules_eval<Connect2>(cells, action, next_cells, legal_mask, terminal); return 0;
+    }
+    return fail(AZSP_ERR_ARG, "unknown game id %d", game);
 }
 
 int32_t azsp_record_bytes(int32_t game) {

@@ -47,6 +47,25 @@ def resnet_flops_per_board(blocks: int, ch: int, cells: int = 42, actions: int =
     return 2.0 * (conv + fc)
 
 
+def tree_report(st: dict, wall_s: float) -> dict:
+    """Selection/expansion/backup kernels: HBM-bound graph work.  Algorithmic bytes per
+    simulation with d levels selected and A = 7 children: select d*A*20 (N, W, P, child index per child) + leaf
+    step 32 + expand A*20 + 24 + path/backup (d + 1)*24; achieved = bytes / summed kernel time (HIP events on the
+    engine streams; the kernels of one slot group run concurrently with the other groups' inference)."""
+    sims = int(st["evals"] + st["terminal_leaves"])
+    depth = st["path_nodes"] / max(sims, 1) - 1.0
+    bytes_per_sim = depth * 7 * 20 + 32 + (7 * 20 + 24) + (depth + 1.0) * 24
+    k_ms = st["select_ms"] + st["expand_ms"]
+    gbs = sims * bytes_per_sim / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    return {"select_ms": st["select_ms"], "expand_ms": st["expand_ms"], "play_ms": st["play_ms"],
+            "rounds": int(st["rounds"]), "evals": int(st["evals"]), "terminal_leaves": int(st["terminal_leaves"]),
+            "path_nodes": int(st["path_nodes"]), "sims_per_s": sims / wall_s, "evals_per_s": st["evals"] / wall_s,
+            "mean_levels_selected": depth,
+            "roofline": {"bound": "hbm", "kernels": "k_select + k_compact + k_expand", "bytes_per_sim": bytes_per_sim,
+                         "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                         "traffic": (pmc_traffic("k_select") or 0) + (pmc_traffic("k_expand") or 0) or None}}
+
+
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate
     --pmc passes, FETCH_SIZE doubled per the gfx950 correction); None if no summary is present."""
@@ -192,9 +211,7 @@ def main() -> None:
                          "boards_per_launch": st["infer_boards"] / launches, "avg_launch_ms": avg_ms, "launches": launches,
                          "concurrent_launches": overlap, "busy_ms": union_ms,
                          "infer_share_of_wall": union_ms * 1e-3 / dt if dt > 0 else None},
-            "tree": {"select_ms": st["select_ms"], "expand_ms": st["expand_ms"], "play_ms": st["play_ms"],
-                     "rounds": int(st["rounds"]), "evals": int(st["evals"]),
-                     "terminal_leaves": int(st["terminal_leaves"]), "path_nodes": int(st["path_nodes"])},
+            "tree": tree_report(st, dt),
         }
 
     head = measure(args.precision)

@@ -107,6 +107,14 @@ const char *azsp_last_error(void);
 /* geometry of the selected game: BaseGame.get_board_size / get_action_size (base_game.py:17-25) */
 int  azsp_game_info(int32_t game, int32_t *rows, int32_t *cols, int32_t *n_actions, int32_t *max_plies);
 
+/* The device game trait evaluated on the HOST (the trait code in csrc/azsp_games.h is shared by host and
+ * device): for a canonical board, the legal-move bit mask (get_valid_moves, connect4_game.py:48-56), the
+ * reward for the side to move (get_reward_for_player(board, +1), :90-98; 2 = game not over) and the canonical
+ * board after `action` by the side to move, seen by the opponent (get_next_state + get_canonical_board(-1),
+ * :28-42,:100-101).  No GPU needed: this is what the CPU conformance test pins against the reference fixtures. */
+int  azsp_game_rules(int32_t game, const int8_t *cells, int32_t action, int8_t *next_cells, int32_t *legal_mask,
+                     int32_t *terminal);
+
 /* ---- evaluator ------------------------------------------------------------------------------ */
 /* Upload ResNet weights.  `blob` is the float32 concatenation, in this order, of the state_dict
  * tensors of src/alphazero_simple/resnet.py:44-72 (each tensor row-major as PyTorch stores it):

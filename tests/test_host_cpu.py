@@ -143,3 +143,27 @@ def test_shard_allowances_reproduce_the_global_first_n_rule():
             assert stop == [r for r, (lo, hi) in enumerate(ranges) if lo <= last < hi][0]
         else:
             assert stop is None
+
+
+@pytest.mark.parametrize("fname,gid,A", [("rules_connect4.json", 0, 7), ("rules_connect2.json", 1, 4)])
+def test_device_game_traits_match_reference_on_host(fname, gid, A):
+    """The bitboard traits the kernels run (csrc/azsp_games.h, shared host/device code) evaluated on the CPU
+    through azsp_game_rules against every rule vector recorded from the reference -- including full columns,
+    gravity-violating and over-full boards."""
+    import ctypes as C
+    lib = _lib.load()
+    for c in load_json(fname)["cases"]:
+        for player in (1, -1):
+            canon = (player * np.array(c["board"], dtype=np.int64)).astype(np.int8).reshape(-1)
+            mask, term = C.c_int32(), C.c_int32()
+            nxt = np.zeros_like(canon)
+            action = c["action"] if player == c["player"] else 0
+            assert lib.azsp_game_rules(gid, canon.ctypes.data_as(C.POINTER(C.c_int8)), action,
+                                       nxt.ctypes.data_as(C.POINTER(C.c_int8)), C.byref(mask), C.byref(term)) == 0
+            assert [(mask.value >> a) & 1 for a in range(A)] == c["valid"]
+            rew = c["reward_p"] if player == 1 else c["reward_m"]
+            assert term.value == (2 if rew is None else rew)
+            if player == c["player"]:
+                # reference: next = get_next_state(board, player, action); canonical for the opponent = -player * next
+                expect = (-player * np.array(c["next"], dtype=np.int64)).astype(np.int8).reshape(-1)
+                assert np.array_equal(nxt, expect)
