@@ -2,9 +2,9 @@
 pierreveron/alphazero-implementation (`BaseGame` / `BaseModel` / `MCTS` / `EpisodeGenerator`)."""
 from .config import AlphaZeroConfig
 from .episode import Episode, Sample
-from .games import BaseGame, Connect2Game, Connect4Game
+from .games import BaseGame, Connect2Game, Connect4Game, GomokuGame
 
-__all__ = ["AlphaZeroConfig", "Episode", "Sample", "BaseGame", "Connect2Game", "Connect4Game",
+__all__ = ["AlphaZeroConfig", "Episode", "Sample", "BaseGame", "Connect2Game", "Connect4Game", "GomokuGame",
            "BaseModel", "ResNet", "MCTS", "Node", "EpisodeGenerator", "Engine", "generate_dataset",
            "DeviceReplayBuffer", "save_episodes", "load_episodes", "ShardedEpisodeGenerator",
            "DistributedEpisodeGenerator"]

@@ -133,3 +133,47 @@ class Connect2Game(BaseGame):
 
     def get_reward_for_player(self, board, player):
         return self._reward(board, player)
+
+
+class GomokuGame(BaseGame):
+    """9x9 Gomoku, five (or more) in a row wins -- BASELINE.json configs[4].  The reference ships no such game:
+    this is a NEW plugin written against its BaseGame contract (base_game.py:6-62), with the conventions of its
+    Connect4Game: actions are cell indices row*9 + col, `get_next_state` does no legality check (an occupied
+    cell leaves the board unchanged), a win is tested before a draw."""
+    device_trait = "gomoku9"
+
+    def __init__(self, size: int = 9, win_length: int = 5):
+        if (size, win_length) != (9, 5):
+            raise NotImplementedError("the device trait is 9x9 / five in a row")
+        self.rows = self.columns = size
+        self.win_length = win_length
+        self._windows = _window_table(size, size, win_length)
+
+    def get_init_board(self):
+        return np.zeros((self.rows, self.columns), dtype=int)
+
+    def get_board_size(self):
+        return (self.rows, self.columns)
+
+    def get_action_size(self):
+        return self.rows * self.columns
+
+    def get_next_state(self, board, player, action):
+        b = np.copy(board)
+        r, c = divmod(int(action), self.columns)
+        if b[r, c] == 0:
+            b[r, c] = player
+        return b, -player
+
+    def has_legal_moves(self, board):
+        return bool((np.asarray(board) == 0).any())
+
+    def get_valid_moves(self, board):
+        return [int(v) for v in (np.asarray(board).reshape(-1) == 0)]
+
+    def is_win(self, board, player):
+        cells = np.asarray(board).reshape(-1)[self._windows]
+        return bool((cells == player).all(axis=1).any())
+
+    def get_reward_for_player(self, board, player):
+        return self._reward(board, player)

@@ -9,8 +9,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "_build", "libazoracle.so")
-GAME_ID = {"connect4": 0, "connect2": 1}
-GEOM = {0: (6, 7, 7), 1: (1, 4, 4)}
+GAME_ID = {"connect4": 0, "connect2": 1, "gomoku9": 2}
+GEOM = {0: (6, 7, 7), 1: (1, 4, 4), 2: (9, 9, 81)}
+MAX_PLIES = {0: 42, 1: 4, 2: 81}
 
 PREDICT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int8), C.c_int32, C.POINTER(C.c_float),
                          C.POINTER(C.c_float))
@@ -87,7 +88,7 @@ def generate(game: str, sims: int, n_slots: int, salt: int = 0, seed: int | None
     gid = GAME_ID[game]
     rows, cols, A = GEOM[gid]
     cells = rows * cols
-    max_plies = 42 if gid == 0 else 4
+    max_plies = MAX_PLIES[gid]
     cap = n_slots * max_plies
     trace_cap = n_slots * max_plies * 8 if trace else 0
     o = {"ep_offset": np.zeros(n_slots + 1, np.int64), "ep_slot": np.zeros(n_slots, np.int32),

@@ -74,7 +74,7 @@ from alphazero_simple import monte_carlo_tree_search as ref_mcts  # noqa: E402
 from alphazero_simple.resnet import ResNet  # noqa: E402
 from alphazero_less_simple.core.training.episode_generator import EpisodeGenerator  # noqa: E402
 
-from oracle.az_oracle import C2Rules, C4Rules, HashModel  # noqa: E402  (hash definition only)
+from oracle.az_oracle import C2Rules, C4Rules, G9Rules, HashModel  # noqa: E402  (hash definition only)
 
 
 def dump(name, obj):
@@ -322,10 +322,38 @@ def episodes_resnet():
     dump("episodes_resnet.json", out)
 
 
+def gomoku_hash():
+    """Gomoku 9x9 is not in the reference; its MCTS and EpisodeGenerator are game-agnostic, so they are run
+    here with the NEW GomokuGame plugin (alphazero-implementation_amd/azsp/games.py) and the hash evaluator:
+    the search / generator logic with 81 actions (numpy pairwise np.sum over 81 priors, etc.) is the reference's."""
+    sys.path.insert(0, os.path.join(ROOT, "alphazero-implementation_amd"))
+    from azsp.games import GomokuGame
+    game, rules = GomokuGame(), G9Rules()
+    rng = np.random.RandomState(21)
+    boards = [(game.get_init_board(), 1)] + midgame_boards(game, rng, 5, 40)
+    runs = []
+    for salt, sims in ((0, 1), (0, 30), (4242, 120)):
+        m = ref_mcts.MCTS(game, HashModel(rules, salt), sims)
+        roots = m.run_batch([b for b, _ in boards], [p for _, p in boards])
+        runs.append({"game": "gomoku9", "salt": salt, "sims": sims, "boards": [b.tolist() for b, _ in boards],
+                     "to_plays": [int(p) for _, p in boards], "roots": [node_dump(r, 81) for r in roots]})
+    eps = []
+    for n, sims, seed, salt in ((1, 10, 0, 1), (3, 24, 1, 2)):
+        out = run_reference_generator(game, HashModel(rules, salt), sims, n, seed)
+        out.update({"game": "gomoku9", "n": n, "sims": sims, "seed": seed, "salt": salt})
+        eps.append(out)
+        print(f"  gomoku episodes n={n} sims={sims}: {len(out['episodes'])} episodes, {len(out['plies'])} plies")
+    dump("gomoku_hash.json", {"search": runs, "episodes": eps})
+
+
 if __name__ == "__main__":
+    if "--gomoku" in sys.argv:
+        gomoku_hash()
+        sys.exit(0)
     rules_connect4()
     rules_connect2()
     search_hash()
     episodes_hash()
     resnet_forward()
     episodes_resnet()
+    gomoku_hash()

@@ -274,3 +274,57 @@ def test_reference_mcts_tests_intent_holds_in_the_oracle():
         root = oz.run_batch(rules, FixedPriorModel(priors, value).predict, sims, [np.array(board)], [1])[0]
         counts = oz.root_counts(root, 4)
         assert sum(counts) == sims and check(counts), (priors, counts)
+
+
+# ----------------------------------------------------------------------------------- Gomoku (new plugin game)
+def test_gomoku_search_and_episodes_match_reference_algorithm_with_plugin_game():
+    """tests/golden/gomoku_hash.json: the reference's MCTS.run_batch / generate_episodes run with the NEW 9x9
+    Gomoku BaseGame plugin (81 actions: numpy pairwise np.sum over the priors, 81-way sampling).  Both oracles
+    must reproduce it bit for bit."""
+    g = load("gomoku_hash.json")
+    rules = oz.G9Rules()
+    for run in g["search"]:
+        boards = [np.array(b, dtype=int) for b in run["boards"]]
+        roots = oz.run_batch(rules, oz.HashModel(rules, run["salt"]).predict, run["sims"], boards, run["to_plays"])
+        out = co.run_batch("gomoku9", run["sims"], np.array(run["boards"], dtype=np.int8), run["to_plays"], run["salt"])
+        for i, (r, gr) in enumerate(zip(roots, run["roots"])):
+            _check_root(r, gr, 81)
+            assert out["root_n"][i] == gr["n"] and float(out["root_w"][i]) == gr["w"] and out["n_nodes"][i] == gr["nodes"]
+            for a in range(81):
+                k = gr["kids"].get(str(a))
+                if k is None:
+                    assert out["counts"][i, a] == 0 and out["prior"][i, a] == 0.0
+                else:
+                    assert out["counts"][i, a] == k["n"] and float(out["child_w"][i, a]) == k["w"]
+                    assert float(out["prior"][i, a]) == k["prior"]
+    for run in g["episodes"]:
+        _check_generate(co.generate("gomoku9", run["sims"], run["n"], run["salt"], seed=run["seed"]), run)
+        np.random.seed(run["seed"])
+        eps = list(oz.generate_episodes(rules, oz.HashModel(rules, run["salt"]).predict, run["sims"], run["n"]))
+        assert float(np.random.random_sample()) == run["rng_after"]
+        for ep, ge in zip(eps, run["episodes"]):
+            assert [np.asarray(s).tolist() for s, _, _ in ep] == ge["states"]
+            assert [np.asarray(p).tolist() for _, p, _ in ep] == ge["policies"]
+            assert [int(z) for _, _, z in ep] == ge["values"]
+
+
+def test_host_gomoku_game_matches_oracle_rules():
+    import azsp
+    game, rules = azsp.GomokuGame(), oz.G9Rules()
+    rng = np.random.RandomState(5)
+    for _ in range(30):
+        b, p = game.get_init_board(), 1
+        for _ in range(81):
+            legal = [i for i, v in enumerate(game.get_valid_moves(b)) if v]
+            assert game.get_valid_moves(b) == rules.valid_moves(b)
+            a = int(rng.choice(legal))
+            nb, np_ = game.get_next_state(b, p, a)
+            ob, op = rules.next_state(b, p, a)
+            assert np.array_equal(nb, ob) and np_ == op
+            b, p = nb, np_
+            assert game.get_reward_for_player(b, p) == rules.reward(b, p)
+            assert game.is_win(b, 1) == rules.is_win(b, 1) and game.is_win(b, -1) == rules.is_win(b, -1)
+            if rules.reward(b, p) is not None:
+                break
+    full = np.ones((9, 9), dtype=int)
+    assert np.array_equal(game.get_next_state(full, -1, 40)[0], full)          # occupied cell: no-op
