@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libazsp.so")
 
-GAME_CONNECT4, GAME_CONNECT2 = 0, 1
+GAME_CONNECT4, GAME_CONNECT2, GAME_GOMOKU9 = 0, 1, 2
 EVAL_RESNET, EVAL_HASH, EVAL_HOST = 0, 1, 2
 FLAG_TIMING = 1
 FLAG_F16_SPLIT = 2

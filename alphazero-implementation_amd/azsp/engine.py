@@ -9,14 +9,14 @@ import numpy as np
 
 from . import _lib as L
 
-GAME_IDS = {"connect4": L.GAME_CONNECT4, "connect2": L.GAME_CONNECT2}
+GAME_IDS = {"connect4": L.GAME_CONNECT4, "connect2": L.GAME_CONNECT2, "gomoku9": L.GAME_GOMOKU9}
 
 
 def game_id_of(game) -> int:
     """Map a BaseGame instance (or trait name) to its device trait id."""
     name = game if isinstance(game, str) else getattr(game, "device_trait", None)
     if name is None:      # duck-typed reference game objects: go by class name
-        name = {"Connect4Game": "connect4", "Connect2Game": "connect2"}.get(type(game).__name__)
+        name = {"Connect4Game": "connect4", "Connect2Game": "connect2", "GomokuGame": "gomoku9"}.get(type(game).__name__)
     if name not in GAME_IDS:
         raise NotImplementedError(
             f"{type(game).__name__} has no device trait in libazsp (csrc/azsp_games.h); the engine has no CPU fallback")

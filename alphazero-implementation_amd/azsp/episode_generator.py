@@ -37,7 +37,7 @@ class EpisodeGenerator:
         self.last_stats: dict | None = None
 
     def engine_for(self, model) -> Engine:
-        blocks, ch, salt = engine_geometry_for_model(model)
+        blocks, ch, salt = engine_geometry_for_model(model, self.game)
         key = (self.config.num_episodes, self.config.num_simulations, blocks, ch, salt, self.f16_split)
         if self._engine is None or key != self._engine_key:
             if self._engine is not None:

@@ -60,11 +60,14 @@ def configure_engine_for_model(engine: Engine, model) -> None:
     engine.use_host_evaluator(model.predict)
 
 
-def engine_geometry_for_model(model) -> tuple[int, int, int]:
-    """(res_blocks, channels, hash_salt) to create an engine for this model."""
+def engine_geometry_for_model(model, game=None) -> tuple[int, int, int]:
+    """(res_blocks, channels, hash_salt) to create an engine for this model.  The device network exists for
+    Connect-4 only (as the reference's ResNet.predict, resnet.py:135); other games evaluate through the host callback."""
     if hasattr(model, "azsp_hash_salt"):
         return 0, 0, int(model.azsp_hash_salt)
     sd = model.state_dict() if hasattr(model, "state_dict") else None
+    if game is not None and game_id_of(game) != 0:
+        return 0, 0, 0
     if sd is not None and is_resnet_state_dict(sd):
         _, blocks, ch = resnet_blob(sd)
         if 1 <= (ch + 31) // 32 <= 4:
@@ -87,7 +90,7 @@ class MCTS:
         if self._engine is None or self._engine.n_slots < n:
             if self._engine is not None:
                 self._engine.close()
-            blocks, ch, salt = engine_geometry_for_model(self.model)
+            blocks, ch, salt = engine_geometry_for_model(self.model, self.game)
             self._engine = Engine(self.game, max(n, 64), self.num_simulations, device=default_device(),
                                   res_blocks=blocks, channels=ch, hash_salt=salt)
         configure_engine_for_model(self._engine, self.model)

@@ -64,7 +64,7 @@ class ShardedEpisodeGenerator:
         self._key = None
 
     def _engines_for(self, model) -> list[Engine]:
-        blocks, ch, salt = engine_geometry_for_model(model)
+        blocks, ch, salt = engine_geometry_for_model(model, self.game)
         key = (blocks, ch, salt)
         if self._engines is None or key != self._key:
             for e in self._engines or []:
@@ -140,7 +140,7 @@ class DistributedEpisodeGenerator:
 
     def generate_episodes(self, model) -> Generator[tuple[Episode, int, int], None, None]:
         """Yields (episode, ply, global_slot) for the episodes of this rank's shard."""
-        blocks, ch, salt = engine_geometry_for_model(model)
+        blocks, ch, salt = engine_geometry_for_model(model, self.game)
         lo, hi = self.ranges[self.rank]
         n = self.config.num_episodes
         key = (blocks, ch, salt)

@@ -35,18 +35,26 @@ static int fail(int code, const char *fmt, ...) {
             return fail(AZSP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
-struct GameInfo { int rows, cols, A, cells, max_plies; };
+struct GameInfo { int rows, cols, A, cells, max_plies, W, AP; };
 static bool game_info(int game, GameInfo &gi) {
     switch (game) {
-        case AZSP_GAME_CONNECT4: gi = {Connect4::ROWS, Connect4::COLS, Connect4::A, Connect4::CELLS, Connect4::MAX_PLIES}; return true;
-        case AZSP_GAME_CONNECT2: gi = {Connect2::ROWS, Connect2::COLS, Connect2::A, Connect2::CELLS, Connect2::MAX_PLIES}; return true;
+        case AZSP_GAME_CONNECT4: gi = {Connect4::ROWS, Connect4::COLS, Connect4::A, Connect4::CELLS, Connect4::MAX_PLIES, Connect4::W, Connect4::AP}; return true;
+        case AZSP_GAME_CONNECT2: gi = {Connect2::ROWS, Connect2::COLS, Connect2::A, Connect2::CELLS, Connect2::MAX_PLIES, Connect2::W, Connect2::AP}; return true;
+        case AZSP_GAME_GOMOKU9: gi = {Gomoku9::ROWS, Gomoku9::COLS, Gomoku9::A, Gomoku9::CELLS, Gomoku9::MAX_PLIES, Gomoku9::W, Gomoku9::AP}; return true;
     }
     return false;
 }
 
-static void host_cells_to_bits(int game, const int8_t *cells, u64 &m, u64 &t) {
-    if (game == AZSP_GAME_CONNECT4) cells_to_bits<Connect4>(cells, m, t);
-    else cells_to_bits<Connect2>(cells, m, t);
+template <class G>
+static void host_cells_to_words(const int8_t *cells, u64 *m, u64 *t) {
+    typename G::B bm, bt;
+    cells_to_board<G>(cells, bm, bt);
+    for (int i = 0; i < G::W; ++i) { m[i] = bm.w[i]; t[i] = bt.w[i]; }
+}
+static void host_cells_to_bits(int game, const int8_t *cells, u64 *m, u64 *t) {
+    if (game == AZSP_GAME_CONNECT4) host_cells_to_words<Connect4>(cells, m, t);
+    else if (game == AZSP_GAME_CONNECT2) host_cells_to_words<Connect2>(cells, m, t);
+    else host_cells_to_words<Gomoku9>(cells, m, t);
 }
 
 enum { EV_INFER = 0, EV_SELECT = 1, EV_EXPAND = 2, EV_PLAY = 3, EV_KINDS = 4 };
@@ -171,7 +179,7 @@ static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
             if (!e->net || !e->net_loaded) return fail(AZSP_ERR_STATE, "ResNet evaluator selected but no weights loaded (azsp_load_resnet)");
             EventPair *p = ev_begin(e, EV_INFER, st);
             resnet_forward(e->net, game, v.leaf_mine, v.leaf_theirs, v.leaf_slot + v.lo, v.n_leaf + v.grp, v.n_act,
-                           v.eval_p + (size_t)v.lo * PSTRIDE, v.eval_v + v.lo, st);
+                           v.eval_p + (size_t)v.lo * PSTRIDE, v.eval_v + v.lo, st);   // ResNet: Connect-4 only, AP == PSTRIDE
             ev_end(p, st);
             e->stats.infer_launches++;
             return 0;
@@ -179,7 +187,7 @@ static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
         case AZSP_EVAL_HOST: {
             if (!e->cb) return fail(AZSP_ERR_STATE, "host evaluator selected but no callback set");
             if (v.lo != 0) return fail(AZSP_ERR_STATE, "host evaluator needs a single slot group");
-            const int A = e->gi.A, cells = e->gi.cells;
+            const int A = e->gi.A, cells = e->gi.cells, AP = e->gi.AP;
             launch_leaf_cells(game, v, e->d_cells, st);
             HIP_TRY(hipMemcpyAsync(e->h_nleaf, v.n_leaf, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -190,8 +198,8 @@ static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
             if (e->cb(e->cb_user, e->h_cells.data(), m, e->h_p.data(), e->h_v.data()))
                 return fail(AZSP_ERR_CALLBACK, "host evaluator callback reported failure");
             for (int j = 0; j < m; ++j)
-                for (int a = 0; a < PSTRIDE; ++a) e->h_p8[(size_t)j * PSTRIDE + a] = a < A ? e->h_p[(size_t)j * A + a] : 0.0f;
-            HIP_TRY(hipMemcpyAsync(v.eval_p, e->h_p8.data(), (size_t)m * PSTRIDE * sizeof(float), hipMemcpyHostToDevice, st));
+                for (int a = 0; a < AP; ++a) e->h_p8[(size_t)j * AP + a] = a < A ? e->h_p[(size_t)j * A + a] : 0.0f;
+            HIP_TRY(hipMemcpyAsync(v.eval_p, e->h_p8.data(), (size_t)m * AP * sizeof(float), hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(v.eval_v, e->h_v.data(), (size_t)m * sizeof(float), hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
             return 0;
@@ -261,14 +269,18 @@ static int search(azsp_engine *e, int n_act) {
 
 template <class G>
 static void rules_eval(const int8_t *cells, int32_t action, int8_t *next_cells, int32_t *legal_mask, int32_t *terminal) {
-    u64 m, t, nm, nt;
-    cells_to_bits<G>(cells, m, t);
-    if (legal_mask) *legal_mask = (int32_t)G::legal_mask(m, t);
+    typename G::B m, t, nm, nt;
+    cells_to_board<G>(cells, m, t);
+    if (legal_mask)                    // int32[(A + 31) / 32] words, bit a = action a is legal
+        for (int a = 0; a < G::A; ++a) {
+            if ((a & 31) == 0) legal_mask[a >> 5] = 0;
+            if (G::legal(m, t, a)) legal_mask[a >> 5] |= (int32_t)(1u << (a & 31));
+        }
     if (terminal) *terminal = G::terminal(m, t);
     if (next_cells) {
         if (action < 0 || action >= G::A) { memcpy(next_cells, cells, G::CELLS); return; }
         G::play(m, t, action, nm, nt);
-        bits_to_cells<G>(nm, nt, next_cells);
+        board_to_cells<G>(nm, nt, next_cells);
     }
 }
 
@@ -297,6 +309,7 @@ int azsp_game_rules(int32_t game, const int8_t *cells, int32_t action, int8_t *n
     switch (game) {
         case AZSP_GAME_CONNECT4: rules_eval<Connect4>(cells, action, next_cells, legal_mask, terminal); return 0;
         case AZSP_GAME_CONNECT2: rules_eval<Connect2>(cells, action, next_cells, legal_mask, terminal); return 0;
+        case AZSP_GAME_GOMOKU9: rules_eval<Gomoku9>(cells, action, next_cells, legal_mask, terminal); return 0;
     }
     return fail(AZSP_ERR_ARG, "unknown game id %d", game);
 }
@@ -343,7 +356,7 @@ static int create_impl(azsp_engine *e) {
     }
     HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     View &v = e->v;
-    const int N = c.n_slots, A = gi.A, S = c.n_sims;
+    const int N = c.n_slots, A = gi.A, S = c.n_sims, W = gi.W, AP = gi.AP;
     const int EPS = c.arena_episodes > N ? c.arena_episodes : N;
     v.cap_eps = EPS;
     v.root_noise = nullptr;
@@ -362,26 +375,26 @@ static int create_impl(azsp_engine *e) {
     v.cells = gi.cells;
     const size_t NC = (size_t)N * v.C, NE = (size_t)N * v.E;
     DEV_ALLOC(v.cnt, NC); DEV_ALLOC(v.wsum, NC); DEV_ALLOC(v.prior, NC); DEV_ALLOC(v.kids, NC);
-    DEV_ALLOC(v.blk_parent, NE); DEV_ALLOC(v.st_mine, NE); DEV_ALLOC(v.st_theirs, NE);
+    DEV_ALLOC(v.blk_parent, NE); DEV_ALLOC(v.st_mine, NE * W); DEV_ALLOC(v.st_theirs, NE * W);
     DEV_ALLOC(v.n_blk, N);
     DEV_ALLOC(v.path, (size_t)N * v.D); DEV_ALLOC(v.path_len, N); DEV_ALLOC(v.leaf_node, N);
-    DEV_ALLOC(v.leaf_mine, N); DEV_ALLOC(v.leaf_theirs, N); DEV_ALLOC(v.pending, N);
+    DEV_ALLOC(v.leaf_mine, (size_t)N * W); DEV_ALLOC(v.leaf_theirs, (size_t)N * W); DEV_ALLOC(v.pending, N);
     DEV_ALLOC(v.leaf_slot, N); DEV_ALLOC(v.n_leaf, MAX_GROUPS);
     HIP_TRY(hipMemset(v.leaf_slot, 0, (size_t)N * sizeof(int32_t)));
     HIP_TRY(hipMemset(v.n_leaf, 0, MAX_GROUPS * sizeof(int32_t)));
-    DEV_ALLOC(v.eval_p, (size_t)N * PSTRIDE); DEV_ALLOC(v.eval_v, N);
+    DEV_ALLOC(v.eval_p, (size_t)N * AP); DEV_ALLOC(v.eval_v, N);
     double *sq = nullptr;
     DEV_ALLOC(sq, S + 2);
     v.sqrt_tab = sq;
-    DEV_ALLOC(v.cur_mine, N); DEV_ALLOC(v.cur_theirs, N); DEV_ALLOC(v.cur_len, N);
+    DEV_ALLOC(v.cur_mine, (size_t)N * W); DEV_ALLOC(v.cur_theirs, (size_t)N * W); DEV_ALLOC(v.cur_len, N);
     const size_t NH = (size_t)N * gi.max_plies, NA = (size_t)EPS * gi.max_plies;
-    DEV_ALLOC(v.h_mine, NH); DEV_ALLOC(v.h_theirs, NH); DEV_ALLOC(v.h_counts, NH * LANES);
+    DEV_ALLOC(v.h_mine, NH * W); DEV_ALLOC(v.h_theirs, NH * W); DEV_ALLOC(v.h_counts, NH * AP);
     DEV_ALLOC(v.done, N); DEV_ALLOC(v.reward, N); DEV_ALLOC(v.chosen, N); DEV_ALLOC(v.emit_off, N);
     DEV_ALLOC(v.ep_offset, EPS + 1); DEV_ALLOC(v.ep_slot, EPS); DEV_ALLOC(v.ep_ply, EPS);
     DEV_ALLOC(v.out_states, NA * gi.cells); DEV_ALLOC(v.out_policies, NA * A); DEV_ALLOC(v.out_values, NA);
     DEV_ALLOC(v.totals, 4); DEV_ALLOC(v.counters, 8);
     DEV_ALLOC(e->d_uniforms, N); DEV_ALLOC(e->d_cells, (size_t)N * gi.cells);
-    DEV_ALLOC(e->d_tmp_mine, N); DEV_ALLOC(e->d_tmp_theirs, N);
+    DEV_ALLOC(e->d_tmp_mine, (size_t)N * W); DEV_ALLOC(e->d_tmp_theirs, (size_t)N * W);
     DEV_ALLOC(e->d_st_counts, (size_t)N * A); DEV_ALLOC(e->d_st_w, (size_t)N * A); DEV_ALLOC(e->d_st_prior, (size_t)N * A);
     DEV_ALLOC(e->d_st_rw, N); DEV_ALLOC(e->d_st_rn, N);
     DEV_ALLOC(e->d_noise, (size_t)N * A);
@@ -400,9 +413,9 @@ static int create_impl(azsp_engine *e) {
     e->h_cells.resize((size_t)N * gi.cells);
     e->h_p.resize((size_t)N * A);
     e->h_v.resize(N);
-    e->h_p8.resize((size_t)N * PSTRIDE);
-    e->h_mine.resize(N);
-    e->h_theirs.resize(N);
+    e->h_p8.resize((size_t)N * AP);
+    e->h_mine.resize((size_t)N * W);
+    e->h_theirs.resize((size_t)N * W);
     if (c.res_blocks > 0 && c.channels > 0) {
         e->net = resnet_create(c.game, c.res_blocks, c.channels, (c.flags & AZSP_FLAG_F16_SPLIT) != 0);
         if (!e->net) return fail(AZSP_ERR_ARG, "unsupported ResNet geometry: %d blocks x %d channels", c.res_blocks, c.channels);
@@ -464,9 +477,11 @@ int azsp_sync(azsp_engine *e) {
 }
 
 static int upload_boards(azsp_engine *e, const int8_t *boards, int n) {
-    for (int i = 0; i < n; ++i) host_cells_to_bits(e->cfg.game, boards + (size_t)i * e->gi.cells, e->h_mine[i], e->h_theirs[i]);
-    HIP_TRY(hipMemcpyAsync(e->d_tmp_mine, e->h_mine.data(), (size_t)n * sizeof(u64), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->d_tmp_theirs, e->h_theirs.data(), (size_t)n * sizeof(u64), hipMemcpyHostToDevice, e->stream));
+    const int W = e->gi.W;
+    for (int i = 0; i < n; ++i)
+        host_cells_to_bits(e->cfg.game, boards + (size_t)i * e->gi.cells, &e->h_mine[(size_t)i * W], &e->h_theirs[(size_t)i * W]);
+    HIP_TRY(hipMemcpyAsync(e->d_tmp_mine, e->h_mine.data(), (size_t)n * W * sizeof(u64), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_tmp_theirs, e->h_theirs.data(), (size_t)n * W * sizeof(u64), hipMemcpyHostToDevice, e->stream));
     launch_set_boards(e->cfg.game, e->v, e->d_tmp_mine, e->d_tmp_theirs, n, e->stream);
     HIP_TRY(hipStreamSynchronize(e->stream));      // h_mine/h_theirs are pageable: copies must finish before reuse
     return 0;
@@ -475,7 +490,7 @@ static int upload_boards(azsp_engine *e, const int8_t *boards, int n) {
 int azsp_predict(azsp_engine *e, const int8_t *boards, int32_t n, float *p_out, float *v_out) {
     if (!e || !boards || n < 0) return fail(AZSP_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    const int N = e->cfg.n_slots, A = e->gi.A;
+    const int N = e->cfg.n_slots, A = e->gi.A, AP = e->gi.AP;
     for (int lo = 0; lo < n; lo += N) {
         const int m = (n - lo < N) ? n - lo : N;
         int rc = upload_boards(e, boards + (size_t)lo * e->gi.cells, m);
@@ -487,12 +502,12 @@ int azsp_predict(azsp_engine *e, const int8_t *boards, int32_t n, float *p_out, 
         launch_compact(e->v, e->stream);
         rc = evaluate_leaves(e, e->v, e->stream);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(e->h_p8.data(), e->v.eval_p, (size_t)m * PSTRIDE * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->h_p8.data(), e->v.eval_p, (size_t)m * AP * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipMemcpyAsync(e->h_v.data(), e->v.eval_v, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         rc = sync_stream(e);
         if (rc) return rc;
         for (int j = 0; j < m; ++j) {
-            if (p_out) for (int a = 0; a < A; ++a) p_out[(size_t)(lo + j) * A + a] = e->h_p8[(size_t)j * PSTRIDE + a];
+            if (p_out) for (int a = 0; a < A; ++a) p_out[(size_t)(lo + j) * A + a] = e->h_p8[(size_t)j * AP + a];
             if (v_out) v_out[lo + j] = e->h_v[j];
         }
     }

@@ -2,10 +2,15 @@
 // (reference: src/alphazero_simple/base_game.py:6-62).  A trait is what a Python BaseGame subclass
 // registers on the device side; every function below is callable from host and device.
 //
-// Bit layout (shared with oracle/az_oracle.py `to_bits` and oracle/az_oracle.c):
-//   cell (row r counted from the TOP, column c)  ->  bit  c*(ROWS+1) + (ROWS-1-r)
-// i.e. column-major with one always-zero sentinel bit above each column, so shift-and
-// line tests cannot wrap between columns.
+// A position is two bit sets (side to move = "mine", opponent = "theirs") of W 64-bit words each.
+//   Connect-4 / Connect2: cell (row r from the TOP, column c) -> bit c*(ROWS+1) + (ROWS-1-r)
+//                         (column-major, one always-zero sentinel bit above each column)
+//   Gomoku 9x9          : cell (r, c) -> bit r*(COLS+1) + c   (row-major, one sentinel column), 90 bits
+// so shift-and line tests cannot wrap.  The same layouts are restated in oracle/az_oracle.py (`to_bits`)
+// and oracle/az_oracle.c for the hash evaluator.
+//
+// Each trait also fixes the thread mapping of the tree kernels: LPG lanes cooperate on one game and every
+// lane owns APL = ceil(A / LPG) actions (lane, lane + LPG, ...).
 #pragma once
 #include <stdint.h>
 
@@ -21,11 +26,39 @@ typedef uint64_t u64;
 
 enum : int { TERM_NONE = 2 };   // terminal(): +1 / -1 / 0 reward for the side to move, or TERM_NONE
 
+template <int W>
+struct Board {
+    u64 w[W];
+};
+
+template <int W>
+AZ_HD Board<W> board_zero() {
+    Board<W> b;
+    for (int i = 0; i < W; ++i) b.w[i] = 0;
+    return b;
+}
+template <int W>
+AZ_HD Board<W> board_load(const u64 *arr, size_t idx) {
+    Board<W> b;
+    for (int i = 0; i < W; ++i) b.w[i] = arr[idx * W + i];
+    return b;
+}
+template <int W>
+AZ_HD void board_store(u64 *arr, size_t idx, const Board<W> &b) {
+    for (int i = 0; i < W; ++i) arr[idx * W + i] = b.w[i];
+}
+template <int W>
+AZ_HD bool board_bit(const Board<W> &b, int bit) { return (b.w[bit >> 6] >> (bit & 63)) & 1ull; }
+template <int W>
+AZ_HD void board_set(Board<W> &b, int bit) { b.w[bit >> 6] |= 1ull << (bit & 63); }
+
 // --------------------------------------------------------------------------------------------
 // Connect-4, 6x7, four in a row.  src/alphazero_simple/connect4_game.py:6-101
 // --------------------------------------------------------------------------------------------
 struct Connect4 {
     static constexpr int ROWS = 6, COLS = 7, A = 7, CELLS = 42, H1 = 7, MAX_PLIES = 42;
+    static constexpr int W = 1, LPG = 8, APL = 1, AP = 8;      // words, lanes per game, actions per lane, padded A
+    typedef Board<1> B;
     static constexpr u64 COL = 0x3Full;
     static constexpr u64 TOP = (1ull << 5) | (1ull << 12) | (1ull << 19) | (1ull << 26) | (1ull << 33) |
                                (1ull << 40) | (1ull << 47);
@@ -38,15 +71,16 @@ struct Connect4 {
         for (int c = 0; c < COLS; ++c) m |= (uint32_t)((free_top >> (c * H1 + 5)) & 1ull) << c;
         return m;
     }
+    static AZ_HD bool legal(const B &m, const B &t, int a) { return !(((m.w[0] | t.w[0]) >> (a * H1 + 5)) & 1ull); }
     // get_next_state(board, player=+1, a) followed by get_canonical_board(.., -1)
     // (connect4_game.py:28-42,100-101; called at monte_carlo_tree_search.py:140-142):
     // the piece goes to the lowest empty cell of the column (none -> board unchanged), then
     // the perspective flips, so the mover's stones become `theirs`.
-    static AZ_HD void play(u64 mine, u64 theirs, int a, u64 &nmine, u64 &ntheirs) {
-        u64 col = ((mine | theirs) >> (a * H1)) & COL;
+    static AZ_HD void play(const B &m, const B &t, int a, B &nm, B &nt) {
+        u64 col = ((m.w[0] | t.w[0]) >> (a * H1)) & COL;
         u64 low0 = (col + 1) & ~col & COL;          // lowest zero bit of the 6-cell column, 0 if full
-        nmine = theirs;
-        ntheirs = mine | (low0 << (a * H1));
+        nm.w[0] = t.w[0];
+        nt.w[0] = m.w[0] | (low0 << (a * H1));
     }
     static AZ_HD bool four(u64 b) {                  // is_win, connect4_game.py:58-88
         u64 v = b & (b >> 1);  if (v & (v >> 2)) return true;      // vertical
@@ -56,10 +90,10 @@ struct Connect4 {
         return false;
     }
     // get_reward_for_player(board, +1), connect4_game.py:90-98 (win tested before draw)
-    static AZ_HD int terminal(u64 mine, u64 theirs) {
-        if (four(mine)) return 1;
-        if (four(theirs)) return -1;
-        if (~(mine | theirs) & TOP) return TERM_NONE;               // has_legal_moves :44-46
+    static AZ_HD int terminal(const B &m, const B &t) {
+        if (four(m.w[0])) return 1;
+        if (four(t.w[0])) return -1;
+        if (~(m.w[0] | t.w[0]) & TOP) return TERM_NONE;             // has_legal_moves :44-46
         return 0;
     }
     static AZ_HD int bit_of(int r, int c) { return c * H1 + (ROWS - 1 - r); }
@@ -70,44 +104,101 @@ struct Connect4 {
 // --------------------------------------------------------------------------------------------
 struct Connect2 {
     static constexpr int ROWS = 1, COLS = 4, A = 4, CELLS = 4, H1 = 2, MAX_PLIES = 4;
+    static constexpr int W = 1, LPG = 8, APL = 1, AP = 8;
+    typedef Board<1> B;
     static constexpr u64 ALL = 0x55ull;
 
-    static AZ_HD uint32_t legal_mask(u64 mine, u64 theirs) {        // :44-52
-        u64 e = ~(mine | theirs) & ALL;
-        return (uint32_t)((e & 1) | ((e >> 1) & 2) | ((e >> 2) & 4) | ((e >> 3) & 8));
-    }
-    static AZ_HD void play(u64 mine, u64 theirs, int a, u64 &nmine, u64 &ntheirs) {   // :28-36
+    static AZ_HD bool legal(const B &m, const B &t, int a) { return !(((m.w[0] | t.w[0]) >> (a * H1)) & 1ull); }   // :44-52
+    static AZ_HD void play(const B &m, const B &t, int a, B &nm, B &nt) {   // :28-36
         u64 bit = 1ull << (a * H1);                 // b[action] = player, unconditionally
-        nmine = theirs & ~bit;
-        ntheirs = mine | bit;
+        nm.w[0] = t.w[0] & ~bit;
+        nt.w[0] = m.w[0] | bit;
     }
     static AZ_HD bool two(u64 b) { return (b & (b >> 2)) != 0; }    // :54-66
-    static AZ_HD int terminal(u64 mine, u64 theirs) {               // :68-78
-        if (two(mine)) return 1;
-        if (two(theirs)) return -1;
-        if (~(mine | theirs) & ALL) return TERM_NONE;
+    static AZ_HD int terminal(const B &m, const B &t) {             // :68-78
+        if (two(m.w[0])) return 1;
+        if (two(t.w[0])) return -1;
+        if (~(m.w[0] | t.w[0]) & ALL) return TERM_NONE;
         return 0;
     }
     static AZ_HD int bit_of(int r, int c) { (void)r; return c * H1; }
 };
 
-// int8 cells (row-major, row 0 = top, +1 mine / -1 theirs) <-> bitboards
+// --------------------------------------------------------------------------------------------
+// Gomoku 9x9, five in a row (BASELINE.json configs[4]).  NOT in the reference: the device side of the NEW
+// BaseGame plugin alphazero-implementation_amd/azsp/games.py `GomokuGame` (action = row*9 + col, an occupied
+// cell leaves the board unchanged, win tested before draw -- the conventions of the reference's Connect4Game).
+// --------------------------------------------------------------------------------------------
+struct Gomoku9 {
+    static constexpr int ROWS = 9, COLS = 9, A = 81, CELLS = 81, H1 = 10, MAX_PLIES = 81;
+    static constexpr int W = 2, LPG = 64, APL = 2, AP = 88;
+    typedef Board<2> B;
+
+    static AZ_HD int bit_of(int r, int c) { return r * H1 + c; }
+    static AZ_HD bool legal(const B &m, const B &t, int a) {
+        const int bit = bit_of(a / COLS, a % COLS);
+        return !(board_bit(m, bit) | board_bit(t, bit));
+    }
+    static AZ_HD void play(const B &m, const B &t, int a, B &nm, B &nt) {
+        nm = t;
+        nt = m;
+        const int bit = bit_of(a / COLS, a % COLS);
+        if (!(board_bit(m, bit) | board_bit(t, bit))) board_set(nt, bit);
+    }
+    static AZ_HD B shr(const B &b, int s) {          // 128-bit logical shift right, 0 < s < 64
+        B r;
+        r.w[0] = (b.w[0] >> s) | (b.w[1] << (64 - s));
+        r.w[1] = b.w[1] >> s;
+        return r;
+    }
+    static AZ_HD bool five(const B &b) {
+        const int dirs[4] = {1, H1, H1 + 1, H1 - 1};               // horizontal, vertical, diagonal, anti-diagonal
+        for (int d = 0; d < 4; ++d) {
+            const int s = dirs[d];
+            B x = b;
+            for (int i = 1; i < 5; ++i) {
+                const B sh = shr(b, s * i);
+                x.w[0] &= sh.w[0];
+                x.w[1] &= sh.w[1];
+            }
+            if (x.w[0] | x.w[1]) return true;
+        }
+        return false;
+    }
+    static AZ_HD int terminal(const B &m, const B &t) {
+        if (five(m)) return 1;
+        if (five(t)) return -1;
+        // any empty cell left?  occupied = 81 real cells (sentinel bits are never set)
+        const u64 o0 = m.w[0] | t.w[0], o1 = m.w[1] | t.w[1];
+        u64 full0 = 0, full1 = 0;
+        for (int r = 0; r < ROWS; ++r)
+            for (int c = 0; c < COLS; ++c) {
+                const int bit = bit_of(r, c);
+                if (bit < 64) full0 |= 1ull << bit; else full1 |= 1ull << (bit - 64);
+            }
+        if ((~o0 & full0) | (~o1 & full1)) return TERM_NONE;
+        return 0;
+    }
+};
+
+// int8 cells (row-major, row 0 = top, +1 mine / -1 theirs) <-> bit sets
 template <class G>
-AZ_HD void cells_to_bits(const int8_t *cells, u64 &mine, u64 &theirs) {
-    mine = theirs = 0;
+AZ_HD void cells_to_board(const int8_t *cells, typename G::B &mine, typename G::B &theirs) {
+    mine = board_zero<G::W>();
+    theirs = board_zero<G::W>();
     for (int r = 0; r < G::ROWS; ++r)
         for (int c = 0; c < G::COLS; ++c) {
             int8_t v = cells[r * G::COLS + c];
-            if (v > 0) mine |= 1ull << G::bit_of(r, c);
-            else if (v < 0) theirs |= 1ull << G::bit_of(r, c);
+            if (v > 0) board_set(mine, G::bit_of(r, c));
+            else if (v < 0) board_set(theirs, G::bit_of(r, c));
         }
 }
 template <class G>
-AZ_HD void bits_to_cells(u64 mine, u64 theirs, int8_t *cells) {
+AZ_HD void board_to_cells(const typename G::B &mine, const typename G::B &theirs, int8_t *cells) {
     for (int r = 0; r < G::ROWS; ++r)
         for (int c = 0; c < G::COLS; ++c) {
             int b = G::bit_of(r, c);
-            cells[r * G::COLS + c] = (int8_t)(((mine >> b) & 1) ? 1 : (((theirs >> b) & 1) ? -1 : 0));
+            cells[r * G::COLS + c] = (int8_t)(board_bit(mine, b) ? 1 : (board_bit(theirs, b) ? -1 : 0));
         }
 }
 
@@ -120,26 +211,27 @@ AZ_HD u64 mix64(u64 z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-// p_out[A] (float32, exact zeros on illegal actions), returns V
-template <int A>
-AZ_HD float hash_eval(u64 mine, u64 theirs, uint32_t legal, u64 salt, float *p_out) {
-    u64 h0 = mix64(mine ^ mix64(theirs) ^ salt);
-    uint32_t w[A];
+template <int W>
+AZ_HD u64 board_fold(const Board<W> &b) {          // boards of several words are folded; identity for one word
+    u64 h = b.w[0];
+    for (int k = 1; k < W; ++k) h = mix64(h) ^ b.w[k];
+    return h;
+}
+template <class G>
+AZ_HD uint32_t hash_weight(u64 h0, const typename G::B &m, const typename G::B &t, int a) {
+    if (!G::legal(m, t, a)) return 0u;
+    const u64 r = mix64(h0 + (u64)a + 1ull) >> 52;
+    return 1u + (uint32_t)((r * r * r) >> 24);
+}
+// p_out[a * stride] for a < A (float32, exact zeros on illegal actions), returns V
+template <class G>
+AZ_HD float hash_eval(const typename G::B &m, const typename G::B &t, u64 salt, float *p_out) {
+    const u64 h0 = mix64(board_fold(m) ^ mix64(board_fold(t)) ^ salt);
     uint32_t s = 0;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        uint32_t wa = 0;
-        if ((legal >> a) & 1u) {
-            u64 r = mix64(h0 + (u64)a + 1ull) >> 52;
-            wa = 1u + (uint32_t)((r * r * r) >> 24);
-        }
-        w[a] = wa;
-        s += wa;
-    }
-    float fs = (float)s;
-#pragma unroll
-    for (int a = 0; a < A; ++a) p_out[a] = (float)w[a] / fs;      // IEEE correctly-rounded f32 divide
-    int vi = (int)(mix64(h0 + 0x1000ull) >> 48) - 32768;
+    for (int a = 0; a < G::A; ++a) s += hash_weight<G>(h0, m, t, a);
+    const float fs = (float)s;
+    for (int a = 0; a < G::A; ++a) p_out[a] = (float)hash_weight<G>(h0, m, t, a) / fs;   // IEEE correctly-rounded f32 divide
+    const int vi = (int)(mix64(h0 + 0x1000ull) >> 48) - 32768;
     return (float)vi / 32768.0f;                                   // exact
 }
 

@@ -7,8 +7,7 @@
 
 namespace azsp {
 
-constexpr int LANES = 8;     // lanes per game in the tree kernels (one per action, A <= 8)
-constexpr int PSTRIDE = 8;   // floats per policy row in the evaluation buffers
+constexpr int PSTRIDE = 8;   // floats per policy row written by the ResNet kernels (= Connect4::AP)
 constexpr int MAX_GROUPS = 8; // slot groups searched concurrently on separate HIP streams
 
 // Device-resident state of one engine.  Structure-of-arrays; every per-node array is [slot][C].
@@ -38,17 +37,17 @@ struct View {
     double  *prior;     // P  prior (float64; 0 = no child, monte_carlo_tree_search.py:87)
     int32_t *kids;      // first-child index
     int32_t *blk_parent;    // [n_slots][E]
-    u64     *st_mine, *st_theirs;   // [n_slots][E]
+    u64     *st_mine, *st_theirs;   // [n_slots][E][W]   (W = 64-bit words per side, from the game trait)
     int32_t *n_blk;         // [n_slots]
     // per-round scratch
     int32_t *path;          // [n_slots][D]  root .. leaf of the current descent
     int32_t *path_len;      // [n_slots]     0 for a root expansion (no backup)
     int32_t *leaf_node;     // [n_slots]
-    u64     *leaf_mine, *leaf_theirs;   // [n_slots] canonical position at the leaf
+    u64     *leaf_mine, *leaf_theirs;   // [n_slots][W] canonical position at the leaf
     uint8_t *pending;       // [n_slots] leaf awaits evaluation
     int32_t *leaf_slot;     // [n_slots] per group, at offset lo: compacted (slot order) list of pending slots
     int32_t *n_leaf;        // [MAX_GROUPS]
-    float   *eval_p;        // [n_slots][PSTRIDE] evaluator output, at offset lo, indexed by compacted leaf
+    float   *eval_p;        // [n_slots][AP] evaluator output (AP = A padded to 8), at offset lo, indexed by compacted leaf
     float   *eval_v;        // [n_slots]
     const double *sqrt_tab; // [n_sims + 2] host-computed sqrt(i): bit-identical to math.sqrt
     // search options beyond the reference (all off by default)
@@ -56,10 +55,10 @@ struct View {
     double  noise_eps, noise_keep;   // eps and (1 - eps), both computed on the host
     int32_t sampling_plies;     // < 0: always sample (reference behaviour)
     // live games
-    u64     *cur_mine, *cur_theirs;     // [n_slots] canonical position (side to move = mine)
+    u64     *cur_mine, *cur_theirs;     // [n_slots][W] canonical position (side to move = mine)
     int32_t *cur_len;                   // [n_slots] plies played in the current game
-    u64     *h_mine, *h_theirs;         // [n_slots][max_plies] history: root positions
-    int32_t *h_counts;                  // [n_slots][max_plies][LANES] root child visit counts
+    u64     *h_mine, *h_theirs;         // [n_slots][max_plies][W] history: root positions
+    int32_t *h_counts;                  // [n_slots][max_plies][AP] root child visit counts
     uint8_t *done;                      // [n_slots] game ended this ply
     int8_t  *reward;                    // [n_slots] reward for the side to move at the end
     int32_t *chosen;                    // [n_slots] action sampled this ply

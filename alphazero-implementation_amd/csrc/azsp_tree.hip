@@ -1,14 +1,16 @@
 // Tree kernels of the self-play engine (gfx950).  Compiled with -ffp-contract=off: every float64 /
 // float32 operation below must round exactly like the reference's numpy/Python arithmetic.
 //
-// Thread mapping: 8 lanes per game (one lane per action), 8 games per 64-lane wavefront, one
-// wavefront per workgroup.  Lanes of a game cooperate with width-8 shuffles; the descent path of
-// each game is staged in LDS and flushed to HBM for the expand/backup kernel.
+// Thread mapping (from the game trait): LPG lanes cooperate on one game, each lane owning the actions
+// lane, lane + LPG, ... (Connect-4: 8 lanes x 1 action, 8 games per 64-lane wavefront; Gomoku 9x9:
+// 64 lanes x 2 actions, one game per wavefront); one wavefront per workgroup.  Lanes of a game cooperate
+// with width-LPG shuffles; the descent path of each game is staged in LDS and flushed to HBM for the
+// expand/backup kernel.
 //
 // Reference functions restated (src/alphazero_simple/monte_carlo_tree_search.py unless noted):
 //   k_select        ucb_score :11-22, Node.select_child :63-78, descent + leaf step :129-152,
 //                   terminal backup :150-152 -> MCTS.backpropagate :214-223
-//   k_expand        mask/renormalise :119-121,:165-167, Node.expand :80-90, backpropagate :214-223
+//   k_expand        mask/renormalise :119-121,:165-167 (np.sum order!), Node.expand :80-90, backpropagate :214-223
 //   k_root_prepare  run_batch root section :112-123 (root value discarded)
 //   k_finish        src/alphazero_less_simple/core/training/episode_generator.py:38-59 and
 //                   Node.select_action(temperature=1) :43-61 (np.random.choice = cumsum, normalise,
@@ -22,17 +24,24 @@ namespace azsp {
     switch (game) {                                  \
         case 0: { using G = Connect4; CALL; } break; \
         case 1: { using G = Connect2; CALL; } break; \
+        case 2: { using G = Gomoku9; CALL; } break;  \
         default: break;                              \
     }
 
-static inline int groups_grid(int n_games) { return (n_games * LANES + 63) / 64; }
+template <class G>
+static inline int games_grid(int n_games) { return (n_games * G::LPG + 63) / 64; }
 
-__device__ __forceinline__ double shfl8_d(double x, int src) { return __shfl(x, src, LANES); }
-__device__ __forceinline__ int shfl8_i(int x, int src) { return __shfl(x, src, LANES); }
+template <int LPG>
+__device__ __forceinline__ int red_add(int x) {
+#pragma unroll
+    for (int m = 1; m < LPG; m <<= 1) x += __shfl_xor(x, m, LPG);
+    return x;
+}
 
 // ------------------------------------------------------------------------------------------------
 // root preparation: fresh tree per slot, root queued for evaluation (no backup: path_len = 0)
 // ------------------------------------------------------------------------------------------------
+template <class G>
 __global__ void k_root_prepare(View v) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= v.n_act) return;
@@ -45,8 +54,8 @@ __global__ void k_root_prepare(View v) {
     v.n_blk[g] = 0;
     v.path_len[g] = 0;
     v.leaf_node[g] = 0;
-    v.leaf_mine[g] = v.cur_mine[g];
-    v.leaf_theirs[g] = v.cur_theirs[g];
+    board_store<G::W>(v.leaf_mine, g, board_load<G::W>(v.cur_mine, g));
+    board_store<G::W>(v.leaf_theirs, g, board_load<G::W>(v.cur_theirs, g));
     v.pending[g] = 1;
 }
 
@@ -55,19 +64,19 @@ __global__ void k_root_prepare(View v) {
 // ------------------------------------------------------------------------------------------------
 template <class G>
 __global__ __launch_bounds__(64) void k_select(View v) {
-    constexpr int A = G::A;
-    static_assert(A <= LANES, "one lane per action");
-    extern __shared__ int s_path[];                 // [8 games][D]
-    const int lane = threadIdx.x & (LANES - 1);
-    const int grp = threadIdx.x >> 3;
-    const int gl = blockIdx.x * (64 / LANES) + grp;
+    constexpr int A = G::A, LPG = G::LPG, APL = G::APL, GPW = 64 / LPG;
+    static_assert(APL * LPG >= A, "every action needs a lane slot");
+    extern __shared__ int s_path[];                 // [GPW games][D]
+    const int lane = threadIdx.x & (LPG - 1);
+    const int grp = threadIdx.x / LPG;
+    const int gl = blockIdx.x * GPW + grp;
     const bool live = gl < v.n_act;
     const int g = live ? v.lo + gl : 0;
     const size_t base = (size_t)g * v.C;
     int *my_path = s_path + grp * v.D;
 
     // One dependent round trip per tree level: the lanes fetch N, W, P AND the first-child index of their
-    // child together; the chosen child's first-child index then comes from a shuffle, and N_parent is not
+    // children together; the chosen child's first-child index then comes from a shuffle, and N_parent is not
     // loaded but rebuilt from the children (an expanded node is visited once at expansion and afterwards
     // only on the way to one of its children: N = 1 + sum N_child; the root is never counted at expansion).
     int node = 0, depth = 0, parent_fc = 0, action = 0;
@@ -76,38 +85,51 @@ __global__ __launch_bounds__(64) void k_select(View v) {
     while (true) {
         walking = walking && fc != 0;               // Node.expanded() :35-36
         if (!__any(walking)) break;
-        const bool in = walking && lane < A;
-        const int child = fc + lane;
-        const double p = in ? v.prior[base + child] : 0.0;
-        const int n = in ? v.cnt[base + child] : 0;
-        const float w = in ? v.wsum[base + child] : 0.0f;
-        const int kc = in ? v.kids[base + child] : 0;
-        int np_ = n;
+        double p[APL];
+        int n[APL], kc[APL];
+        float w[APL];
+        int nsum = 0;
 #pragma unroll
-        for (int m = 1; m < LANES; m <<= 1) np_ += __shfl_xor(np_, m, LANES);
-        np_ += node != 0;
-        double score = -INFINITY;
-        if (in && p != 0.0) {                       // a child exists only where prob != 0  (:87)
-            // ucb_score :11-22.  (prior * sqrt(N_parent)) / (n + 1) in float64;
-            // -(W / n) in float32 (numpy 2.x), promoted for the sum.
-            const double u = (p * v.sqrt_tab[np_]) / (double)(n + 1);
-            double q = 0.0;
-            if (n > 0) {
-                const float qf = w / (float)n;
-                q = (double)(-qf);
-            }
-            score = q + u;
-            if (!(score == score)) score = -INFINITY;   // NaN is never '>' the running best
+        for (int k = 0; k < APL; ++k) {
+            const int a = lane + k * LPG;
+            const bool in = walking && a < A;
+            const int child = fc + a;
+            p[k] = in ? v.prior[base + child] : 0.0;
+            n[k] = in ? v.cnt[base + child] : 0;
+            w[k] = in ? v.wsum[base + child] : 0.0f;
+            kc[k] = in ? v.kids[base + child] : 0;
+            nsum += n[k];
         }
-        // argmax, strict '>' in ascending action order == maximum score, lowest action on ties
+        const int np_ = red_add<LPG>(nsum) + (node != 0);
+        double score = -INFINITY;
         int best = lane;
 #pragma unroll
-        for (int m = 1; m < LANES; m <<= 1) {
-            const double so = __shfl_xor(score, m, LANES);
-            const int bo = __shfl_xor(best, m, LANES);
+        for (int k = 0; k < APL; ++k) {
+            if (p[k] != 0.0) {                      // a child exists only where prob != 0  (:87)
+                // ucb_score :11-22.  (prior * sqrt(N_parent)) / (n + 1) in float64;
+                // -(W / n) in float32 (numpy 2.x), promoted for the sum.
+                const double u = (p[k] * v.sqrt_tab[np_]) / (double)(n[k] + 1);
+                double q = 0.0;
+                if (n[k] > 0) {
+                    const float qf = w[k] / (float)n[k];
+                    q = (double)(-qf);
+                }
+                double sc = q + u;
+                if (!(sc == sc)) sc = -INFINITY;    // NaN is never '>' the running best
+                if (sc > score) { score = sc; best = lane + k * LPG; }   // ascending actions within the lane
+            }
+        }
+        // argmax, strict '>' in ascending action order == maximum score, lowest action on ties
+#pragma unroll
+        for (int m = 1; m < LPG; m <<= 1) {
+            const double so = __shfl_xor(score, m, LPG);
+            const int bo = __shfl_xor(best, m, LPG);
             if (so > score || (so == score && bo < best)) { score = so; best = bo; }
         }
-        const int next_fc = __shfl(kc, best, LANES);
+        int kc_sel = kc[0];
+#pragma unroll
+        for (int k = 1; k < APL; ++k) if (best / LPG == k) kc_sel = kc[k];
+        const int next_fc = __shfl(kc_sel, best & (LPG - 1), LPG);
         if (walking) {
             if (lane == 0) my_path[depth] = node;
             parent_fc = fc;
@@ -123,11 +145,11 @@ __global__ __launch_bounds__(64) void k_select(View v) {
 
     // leaf step (:135-145): parent's position + action, flip perspective, terminal test
     int term = TERM_NONE;
-    u64 nm = 0, nt = 0;
+    typename G::B nm = board_zero<G::W>(), nt = board_zero<G::W>();
     if (live) {
         const int e = (parent_fc - 1) / A;
-        const u64 pm = v.st_mine[(size_t)g * v.E + e];
-        const u64 pt = v.st_theirs[(size_t)g * v.E + e];
+        const typename G::B pm = board_load<G::W>(v.st_mine, (size_t)g * v.E + e);
+        const typename G::B pt = board_load<G::W>(v.st_theirs, (size_t)g * v.E + e);
         G::play(pm, pt, action, nm, nt);
         term = G::terminal(nm, nt);
     }
@@ -135,7 +157,7 @@ __global__ __launch_bounds__(64) void k_select(View v) {
         // terminal leaf: never expanded, value in {+1,-1,0}; backpropagate :214-223.  The sign
         // alternates with distance from the leaf (to_play alternates level by level).
         const float val = (float)term;
-        for (int k = lane; k < L; k += LANES) {
+        for (int k = lane; k < L; k += LPG) {
             const int nd = my_path[L - 1 - k];
             const float dv = (k & 1) ? -val : val;
             v.wsum[base + nd] = v.wsum[base + nd] + dv;
@@ -147,13 +169,13 @@ __global__ __launch_bounds__(64) void k_select(View v) {
             atomicAdd(&v.counters[2], (unsigned long long)L);
         }
     } else if (live) {
-        for (int k = lane; k < L; k += LANES) v.path[(size_t)g * v.D + k] = my_path[k];
+        for (int k = lane; k < L; k += LPG) v.path[(size_t)g * v.D + k] = my_path[k];
         if (lane == 0) {
             v.pending[g] = 1;
             v.path_len[g] = L;
             v.leaf_node[g] = node;
-            v.leaf_mine[g] = nm;
-            v.leaf_theirs[g] = nt;
+            board_store<G::W>(v.leaf_mine, g, nm);
+            board_store<G::W>(v.leaf_theirs, g, nt);
             atomicAdd(&v.counters[2], (unsigned long long)L);
         }
     }
@@ -195,12 +217,10 @@ __global__ void k_eval_hash(View v, uint64_t salt) {
     if (j >= v.n_leaf[v.grp]) return;
     j += v.lo;
     const int g = v.leaf_slot[j];
-    const u64 m = v.leaf_mine[g], t = v.leaf_theirs[g];
-    float p[G::A];
-    const float val = hash_eval<G::A>(m, t, G::legal_mask(m, t), salt, p);
-#pragma unroll
-    for (int a = 0; a < PSTRIDE; ++a) v.eval_p[(size_t)j * PSTRIDE + a] = a < G::A ? p[a < G::A ? a : 0] : 0.0f;
-    v.eval_v[j] = val;
+    const typename G::B m = board_load<G::W>(v.leaf_mine, g), t = board_load<G::W>(v.leaf_theirs, g);
+    float *p = v.eval_p + (size_t)j * G::AP;
+    v.eval_v[j] = hash_eval<G>(m, t, salt, p);
+    for (int a = G::A; a < G::AP; ++a) p[a] = 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -208,42 +228,68 @@ __global__ void k_eval_hash(View v, uint64_t salt) {
 // ------------------------------------------------------------------------------------------------
 template <class G>
 __global__ __launch_bounds__(64) void k_expand(View v) {
-    constexpr int A = G::A;
-    const int lane = threadIdx.x & (LANES - 1);
-    const int jl = (blockIdx.x * 64 + threadIdx.x) >> 3;
+    constexpr int A = G::A, LPG = G::LPG, APL = G::APL, GPW = 64 / LPG;
+    __shared__ double s_pa[GPW][G::AP];             // staged priors for numpy's pairwise summation
+    const int lane = threadIdx.x & (LPG - 1);
+    const int grp = threadIdx.x / LPG;
+    const int jl = blockIdx.x * GPW + grp;
     const bool live = jl < v.n_leaf[v.grp];
     const int j = v.lo + (live ? jl : 0);
     const int g = v.leaf_slot[j];
     const size_t base = (size_t)g * v.C;
-    const u64 mine = v.leaf_mine[g], theirs = v.leaf_theirs[g];
-    const uint32_t legal = G::legal_mask(mine, theirs);
+    const typename G::B mine = board_load<G::W>(v.leaf_mine, g), theirs = board_load<G::W>(v.leaf_theirs, g);
 
-    // action_probs * valid_moves -> float64 ; /= np.sum (sequential for < 8 elements)
-    double pa = 0.0;
-    if (live && lane < A) pa = (double)v.eval_p[(size_t)j * PSTRIDE + lane] * (double)((legal >> lane) & 1u);
-    double s = 0.0;
+    // action_probs * valid_moves -> float64 ; /= np.sum(action_probs)
+    double pa[APL];
 #pragma unroll
-    for (int a = 0; a < A; ++a) s = s + shfl8_d(pa, a);
-    const double pr = pa / s;
+    for (int k = 0; k < APL; ++k) {
+        const int a = lane + k * LPG;
+        pa[k] = 0.0;
+        if (live && a < A) pa[k] = (double)v.eval_p[(size_t)j * G::AP + a] * (double)(G::legal(mine, theirs, a) ? 1 : 0);
+        if (a < G::AP) s_pa[grp][a] = pa[k];
+    }
+    __syncthreads();
+    double s = 0.0;
+    if constexpr (A < 8) {                          // numpy: plain left-to-right loop for fewer than 8 elements
+#pragma unroll
+        for (int a = 0; a < A; ++a) s = s + s_pa[grp][a];
+    } else {
+        // numpy pairwise_sum (n <= 128): eight running sums over strides of 8, combined as
+        // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the n % 8 tail one element at a time
+        constexpr int NB = A - (A % 8);
+        double r = 0.0;
+        if (lane < 8) {
+            r = s_pa[grp][lane];
+            for (int i = 8; i < NB; i += 8) r = r + s_pa[grp][i + lane];
+        }
+        const double r0 = __shfl(r, 0, LPG), r1 = __shfl(r, 1, LPG), r2 = __shfl(r, 2, LPG), r3 = __shfl(r, 3, LPG);
+        const double r4 = __shfl(r, 4, LPG), r5 = __shfl(r, 5, LPG), r6 = __shfl(r, 6, LPG), r7 = __shfl(r, 7, LPG);
+        s = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (int i = NB; i < A; ++i) s = s + s_pa[grp][i];
+    }
     if (!live) return;
 
     const int node = v.leaf_node[g];
-    const int e = v.n_blk[g];                       // read by all 8 lanes before lane 0 bumps it
+    const int e = v.n_blk[g];                       // read by all lanes before lane 0 bumps it
     const int fc = 1 + e * A;
     const int L = v.path_len[g];
-    double prior = pr;
-    // optional root exploration noise (off by default; not in the reference's search, listed in its
-    // src/deepmind_alphazero_pseudocode.py:285-290): prior*(1-eps) + noise*eps on the existing root children
-    if (L == 0 && v.root_noise != nullptr && lane < A && pr != 0.0)
-        prior = pr * v.noise_keep + v.root_noise[(size_t)g * A + lane] * v.noise_eps;
-    if (lane < A) {                                 // Node.expand :80-90
-        v.cnt[base + fc + lane] = 0;
-        v.wsum[base + fc + lane] = 0.0f;
-        v.prior[base + fc + lane] = prior;
-        v.kids[base + fc + lane] = 0;
+#pragma unroll
+    for (int k = 0; k < APL; ++k) {
+        const int a = lane + k * LPG;
+        if (a >= A) continue;
+        const double pr = pa[k] / s;
+        double prior = pr;
+        // optional root exploration noise (off by default; not in the reference's search, listed in its
+        // src/deepmind_alphazero_pseudocode.py:285-290): prior*(1-eps) + noise*eps on the existing root children
+        if (L == 0 && v.root_noise != nullptr && pr != 0.0)
+            prior = pr * v.noise_keep + v.root_noise[(size_t)g * A + a] * v.noise_eps;
+        v.cnt[base + fc + a] = 0;                   // Node.expand :80-90
+        v.wsum[base + fc + a] = 0.0f;
+        v.prior[base + fc + a] = prior;
+        v.kids[base + fc + a] = 0;
     }
     const float val = v.eval_v[j];
-    for (int k = lane; k < L; k += LANES) {         // backpropagate :214-223
+    for (int k = lane; k < L; k += LPG) {           // backpropagate :214-223
         const int nd = v.path[(size_t)g * v.D + (L - 1 - k)];
         const float dv = (k & 1) ? -val : val;
         v.wsum[base + nd] = v.wsum[base + nd] + dv;
@@ -253,8 +299,8 @@ __global__ __launch_bounds__(64) void k_expand(View v) {
     if (lane == 0) {
         v.kids[base + node] = fc;
         v.blk_parent[(size_t)g * v.E + e] = node;
-        v.st_mine[(size_t)g * v.E + e] = mine;
-        v.st_theirs[(size_t)g * v.E + e] = theirs;
+        board_store<G::W>(v.st_mine, (size_t)g * v.E + e, mine);
+        board_store<G::W>(v.st_theirs, (size_t)g * v.E + e, theirs);
         v.n_blk[g] = e + 1;
         v.pending[g] = 0;
     }
@@ -266,7 +312,7 @@ __global__ void k_leaf_cells(View v, int8_t *dst) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= v.n_leaf[v.grp]) return;
     const int g = v.leaf_slot[v.lo + j];
-    bits_to_cells<G>(v.leaf_mine[g], v.leaf_theirs[g], dst + (size_t)j * G::CELLS);
+    board_to_cells<G>(board_load<G::W>(v.leaf_mine, g), board_load<G::W>(v.leaf_theirs, g), dst + (size_t)j * G::CELLS);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -274,68 +320,72 @@ __global__ void k_leaf_cells(View v, int8_t *dst) {
 // ------------------------------------------------------------------------------------------------
 template <class G>
 __global__ __launch_bounds__(64) void k_finish(View v, const double *uniforms) {
-    constexpr int A = G::A;
-    const int lane = threadIdx.x & (LANES - 1);
-    const int g = (blockIdx.x * 64 + threadIdx.x) >> 3;
-    const bool live = g < v.n_act;
-    const size_t base = (size_t)(live ? g : 0) * v.C;
-    int c = 0, ex = 0;
-    if (live && lane < A) {
-        ex = v.prior[base + 1 + lane] != 0.0;       // root.children keys
-        c = ex ? v.cnt[base + 1 + lane] : 0;
-    }
-    int cs[A], exs[A];
-#pragma unroll
-    for (int a = 0; a < A; ++a) { cs[a] = shfl8_i(c, a); exs[a] = shfl8_i(ex, a); }
-    if (!live) return;
-
+    constexpr int A = G::A, LPG = G::LPG, APL = G::APL, GPW = 64 / LPG;
+    __shared__ int s_cnt[GPW][G::AP];
+    __shared__ unsigned char s_ex[GPW][G::AP];
+    const int lane = threadIdx.x & (LPG - 1);
+    const int grp = threadIdx.x / LPG;
+    const int gl = blockIdx.x * GPW + grp;
+    const bool live = gl < v.n_act;
+    const int g = live ? gl : 0;
+    const size_t base = (size_t)g * v.C;
     const int len = v.cur_len[g];
     const size_t h = (size_t)g * v.max_plies + len;
-    v.h_counts[h * LANES + lane] = c;               // episode_generator.py:45-52 (pi = counts / sum at emit)
-    const u64 mine = v.cur_mine[g], theirs = v.cur_theirs[g];
-    if (lane == 0) { v.h_mine[h] = mine; v.h_theirs[h] = theirs; }
+#pragma unroll
+    for (int k = 0; k < APL; ++k) {
+        const int a = lane + k * LPG;
+        if (a >= G::AP) continue;
+        int c = 0, ex = 0;
+        if (live && a < A) {
+            ex = v.prior[base + 1 + a] != 0.0;      // root.children keys
+            c = ex ? v.cnt[base + 1 + a] : 0;
+        }
+        s_cnt[grp][a] = c;
+        s_ex[grp][a] = (unsigned char)ex;
+        if (live) v.h_counts[h * G::AP + a] = c;    // episode_generator.py:45-52 (pi = counts / sum at emit)
+    }
+    __syncthreads();
+    if (!live || lane != 0) return;
 
-    // Node.select_action(temperature=1) :43-61
+    const typename G::B mine = board_load<G::W>(v.cur_mine, g), theirs = board_load<G::W>(v.cur_theirs, g);
+    board_store<G::W>(v.h_mine, h, mine);
+    board_store<G::W>(v.h_theirs, h, theirs);
+
+    // Node.select_action(temperature=1) :43-61, sequentially in child order like numpy
     double tot = 0.0;
-#pragma unroll
-    for (int a = 0; a < A; ++a) if (exs[a]) tot = tot + (double)cs[a];      // builtin sum(): 0 + d0 + ...
-    double cdf[A], run = 0.0;
-#pragma unroll
-    for (int a = 0; a < A; ++a) { if (exs[a]) run = run + (double)cs[a] / tot; cdf[a] = run; }   // np.cumsum
-    const double last = run;
+    for (int a = 0; a < A; ++a) if (s_ex[grp][a]) tot = tot + (double)s_cnt[grp][a];      // builtin sum(): 0 + d0 + ...
+    double last = 0.0;
+    for (int a = 0; a < A; ++a) if (s_ex[grp][a]) last = last + (double)s_cnt[grp][a] / tot;   // np.cumsum -> cdf[-1]
     const double u = uniforms[g];
     int act = -1, last_ex = 0;
-#pragma unroll
+    double run = 0.0;
     for (int a = 0; a < A; ++a)
-        if (exs[a]) {
+        if (s_ex[grp][a]) {
             last_ex = a;
-            if (act < 0 && !(cdf[a] / last <= u)) act = a;                  // searchsorted(side='right')
+            run = run + (double)s_cnt[grp][a] / tot;
+            if (act < 0 && !(run / last <= u)) act = a;                       // searchsorted(side='right')
         }
     if (act < 0) act = last_ex;
     // optional: after `sampling_plies` plies of a game the move is the arg-max of the visit counts
     // (Node.select_action(temperature=0), :49-50: first maximum in child order); off (< 0) by default
     if (v.sampling_plies >= 0 && len >= v.sampling_plies) {
         int best = -1, bc = -1;
-#pragma unroll
         for (int a = 0; a < A; ++a)
-            if (exs[a] && cs[a] > bc) { bc = cs[a]; best = a; }
+            if (s_ex[grp][a] && s_cnt[grp][a] > bc) { bc = s_cnt[grp][a]; best = a; }
         act = best;
     }
 
-    u64 nm, nt;
+    typename G::B nm, nt;
     G::play(mine, theirs, act, nm, nt);             // episode_generator.py:55-58
     const int term = G::terminal(nm, nt);           // :59 reward for the player now to move
-    if (lane == 0) {
-        v.cur_mine[g] = nm;
-        v.cur_theirs[g] = nt;
-        v.cur_len[g] = len + 1;
-        v.chosen[g] = act;
-        v.done[g] = term != TERM_NONE;
-        v.reward[g] = (int8_t)(term == TERM_NONE ? 0 : term);
-    }
+    board_store<G::W>(v.cur_mine, g, nm);
+    board_store<G::W>(v.cur_theirs, g, nt);
+    v.cur_len[g] = len + 1;
+    v.chosen[g] = act;
+    v.done[g] = term != TERM_NONE;
+    v.reward[g] = (int8_t)(term == TERM_NONE ? 0 : term);
 }
 
-// first-N-completions bookkeeping (episode_generator.py:78-87); one workgroup, slot order
 // number of games that ended this ply (before any cap), for the two-phase play of the sharded exact mode
 __global__ __launch_bounds__(1024) void k_count_done(View v, int32_t *out) {
     __shared__ int s_c[1024];
@@ -351,6 +401,7 @@ __global__ __launch_bounds__(1024) void k_count_done(View v, int32_t *out) {
     if (t == 0) *out = s_c[0];
 }
 
+// first-N-completions bookkeeping (episode_generator.py:78-87); one workgroup, slot order.
 // `cap` >= 0: emit at most `cap` of this ply's completions (slot order) -- the caller owns the stop rule
 // (sharded exact mode); cap < 0: the engine's own first-n_slots rule.
 __global__ __launch_bounds__(1024) void k_emit_scan(View v, PlyResultDev *res, long long cap) {
@@ -425,9 +476,9 @@ __global__ __launch_bounds__(1024) void k_emit_scan(View v, PlyResultDev *res, l
 // copy finished episodes into the arena and restart their slots
 template <class G>
 __global__ __launch_bounds__(64) void k_emit_copy(View v) {
-    constexpr int A = G::A;
-    const int lane = threadIdx.x & (LANES - 1);
-    const int g = (blockIdx.x * 64 + threadIdx.x) >> 3;
+    constexpr int A = G::A, LPG = G::LPG, APL = G::APL, GPW = 64 / LPG;
+    const int lane = threadIdx.x & (LPG - 1);
+    const int g = blockIdx.x * GPW + threadIdx.x / LPG;
     if (g >= v.n_act || !v.done[g]) return;
     const int len = v.cur_len[g];
     const int off = v.emit_off[g];
@@ -435,46 +486,54 @@ __global__ __launch_bounds__(64) void k_emit_copy(View v) {
     if (off >= 0) {
         for (int q = 0; q < len; ++q) {
             const size_t h = (size_t)g * v.max_plies + q;
-            const int c = v.h_counts[h * LANES + lane];
-            int sum = 0;
+            int c[APL], part = 0;
 #pragma unroll
-            for (int a = 0; a < A; ++a) sum += shfl8_i(c, a);
+            for (int k = 0; k < APL; ++k) {
+                const int a = lane + k * LPG;
+                c[k] = a < A ? v.h_counts[h * G::AP + a] : 0;
+                part += c[k];
+            }
+            const int sum = red_add<LPG>(part);
             // pi = counts / np.sum(counts)  (episode_generator.py:45-48): int -> float64 divide
-            if (lane < A) v.out_policies[(size_t)(off + q) * A + lane] = (double)c / (double)sum;
-            const u64 m = v.h_mine[h], t = v.h_theirs[h];
-            for (int cell = lane; cell < G::CELLS; cell += LANES) {
-                const int r = cell / G::COLS, cc = cell % G::COLS;
-                const int b = G::bit_of(r, cc);
-                v.out_states[(size_t)(off + q) * G::CELLS + cell] =
-                    (int8_t)(((m >> b) & 1) ? 1 : (((t >> b) & 1) ? -1 : 0));
+#pragma unroll
+            for (int k = 0; k < APL; ++k) {
+                const int a = lane + k * LPG;
+                if (a < A) v.out_policies[(size_t)(off + q) * A + a] = (double)c[k] / (double)sum;
+            }
+            const typename G::B m = board_load<G::W>(v.h_mine, h), t = board_load<G::W>(v.h_theirs, h);
+            for (int cell = lane; cell < G::CELLS; cell += LPG) {
+                const int b = G::bit_of(cell / G::COLS, cell % G::COLS);
+                v.out_states[(size_t)(off + q) * G::CELLS + cell] = (int8_t)(board_bit(m, b) ? 1 : (board_bit(t, b) ? -1 : 0));
             }
             // value = reward * (-1)**(hist_player != final_player)  (:73-74); players alternate
             if (lane == 0) v.out_values[off + q] = ((len - q) & 1) ? -rew : rew;
         }
     }
     if (lane == 0) {                                // :80-82 fresh game in this slot
-        v.cur_mine[g] = 0;
-        v.cur_theirs[g] = 0;
+        board_store<G::W>(v.cur_mine, g, board_zero<G::W>());
+        board_store<G::W>(v.cur_theirs, g, board_zero<G::W>());
         v.cur_len[g] = 0;
     }
 }
 
+template <class G>
 __global__ void k_reset_slots(View v) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g == 0) { v.totals[0] = 0; v.totals[1] = 0; v.totals[2] = 0; v.ep_offset[0] = 0; }
     if (g >= v.n_slots) return;
-    v.cur_mine[g] = 0;
-    v.cur_theirs[g] = 0;
+    board_store<G::W>(v.cur_mine, g, board_zero<G::W>());
+    board_store<G::W>(v.cur_theirs, g, board_zero<G::W>());
     v.cur_len[g] = 0;
     v.done[g] = 0;
     v.pending[g] = 0;
 }
 
+template <class G>
 __global__ void k_set_boards(View v, const u64 *mine, const u64 *theirs, int n) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
-    v.cur_mine[g] = mine[g];
-    v.cur_theirs[g] = theirs[g];
+    board_store<G::W>(v.cur_mine, g, board_load<G::W>(mine, g));
+    board_store<G::W>(v.cur_theirs, g, board_load<G::W>(theirs, g));
     v.cur_len[g] = 0;
 }
 
@@ -517,15 +576,18 @@ __global__ void k_export_records(View v, long long first, long long n, unsigned 
 template <class G>
 __global__ void k_export_dataset(View v, long long first, long long n, float *planes, float *pol, float *val) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * G::CELLS) return;
-    const long long smp = i / G::CELLS;
-    const int cell = (int)(i % G::CELLS);
+    constexpr int PER = G::CELLS > G::A ? G::CELLS : G::A;
+    if (i >= n * PER) return;
+    const long long smp = i / PER;
+    const int cell = (int)(i % PER);
     const long long src = first + smp;
-    const int8_t c = v.out_states[src * G::CELLS + cell];
-    float *pl = planes + smp * 3 * G::CELLS + cell;
-    pl[0] = c == 0 ? 1.0f : 0.0f;
-    pl[G::CELLS] = c == 1 ? 1.0f : 0.0f;
-    pl[2 * G::CELLS] = c == -1 ? 1.0f : 0.0f;
+    if (cell < G::CELLS) {
+        const int8_t c = v.out_states[src * G::CELLS + cell];
+        float *pl = planes + smp * 3 * G::CELLS + cell;
+        pl[0] = c == 0 ? 1.0f : 0.0f;
+        pl[G::CELLS] = c == 1 ? 1.0f : 0.0f;
+        pl[2 * G::CELLS] = c == -1 ? 1.0f : 0.0f;
+    }
     if (cell < G::A) pol[smp * G::A + cell] = (float)v.out_policies[src * G::A + cell];
     if (cell == 0) val[smp] = (float)v.out_values[src];
 }
@@ -533,38 +595,38 @@ __global__ void k_export_dataset(View v, long long first, long long n, float *pl
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-void launch_root_prepare(int, const View &v, hipStream_t s) {
-    hipLaunchKernelGGL(k_root_prepare, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v);
+void launch_root_prepare(int game, const View &v, hipStream_t s) {
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_root_prepare<G>, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v));
 }
 void launch_select(int game, const View &v, hipStream_t s) {
-    const size_t lds = (size_t)(64 / LANES) * v.D * sizeof(int);
-    GAME_SWITCH(game, hipLaunchKernelGGL(k_select<G>, dim3(groups_grid(v.n_act)), dim3(64), lds, s, v));
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_select<G>, dim3(games_grid<G>(v.n_act)), dim3(64),
+                                         (size_t)(64 / G::LPG) * v.D * sizeof(int), s, v));
 }
 void launch_compact(const View &v, hipStream_t s) { hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, v); }
 void launch_eval_hash(int game, const View &v, uint64_t salt, hipStream_t s) {
     GAME_SWITCH(game, hipLaunchKernelGGL(k_eval_hash<G>, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v, salt));
 }
 void launch_expand(int game, const View &v, hipStream_t s) {
-    GAME_SWITCH(game, hipLaunchKernelGGL(k_expand<G>, dim3(groups_grid(v.n_act)), dim3(64), 0, s, v));
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_expand<G>, dim3(games_grid<G>(v.n_act)), dim3(64), 0, s, v));
 }
 void launch_leaf_cells(int game, const View &v, int8_t *dst, hipStream_t s) {
     GAME_SWITCH(game, hipLaunchKernelGGL(k_leaf_cells<G>, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v, dst));
 }
 void launch_finish(int game, const View &v, const double *uniforms, hipStream_t s) {
-    GAME_SWITCH(game, hipLaunchKernelGGL(k_finish<G>, dim3(groups_grid(v.n_act)), dim3(64), 0, s, v, uniforms));
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_finish<G>, dim3(games_grid<G>(v.n_act)), dim3(64), 0, s, v, uniforms));
 }
 void launch_count_done(const View &v, int32_t *out, hipStream_t s) {
     hipLaunchKernelGGL(k_count_done, dim3(1), dim3(1024), 0, s, v, out);
 }
 void launch_emit(int game, const View &v, PlyResultDev *res, long long cap, hipStream_t s) {
     hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(1024), 0, s, v, res, cap);
-    GAME_SWITCH(game, hipLaunchKernelGGL(k_emit_copy<G>, dim3(groups_grid(v.n_act)), dim3(64), 0, s, v));
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_emit_copy<G>, dim3(games_grid<G>(v.n_act)), dim3(64), 0, s, v));
 }
-void launch_reset_slots(int, const View &v, hipStream_t s) {
-    hipLaunchKernelGGL(k_reset_slots, dim3((v.n_slots + 255) / 256), dim3(256), 0, s, v);
+void launch_reset_slots(int game, const View &v, hipStream_t s) {
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_reset_slots<G>, dim3((v.n_slots + 255) / 256), dim3(256), 0, s, v));
 }
-void launch_set_boards(int, const View &v, const u64 *mine, const u64 *theirs, int n, hipStream_t s) {
-    hipLaunchKernelGGL(k_set_boards, dim3((n + 255) / 256), dim3(256), 0, s, v, mine, theirs, n);
+void launch_set_boards(int game, const View &v, const u64 *mine, const u64 *theirs, int n, hipStream_t s) {
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_set_boards<G>, dim3((n + 255) / 256), dim3(256), 0, s, v, mine, theirs, n));
 }
 void launch_root_stats(int game, const View &v, int32_t *counts, float *child_w, double *prior, float *root_w,
                        int32_t *root_n, hipStream_t s) {
@@ -576,12 +638,14 @@ void launch_export_records(int game, const View &v, int64_t first, int64_t n, vo
     GAME_SWITCH(game, hipLaunchKernelGGL(k_export_records<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v,
                                          (long long)first, (long long)n, (unsigned char *)dst));
 }
-
 void launch_export_dataset(int game, const View &v, int64_t first, int64_t n, float *planes, float *pol, float *val,
                            hipStream_t s) {
     if (n <= 0) return;
-    GAME_SWITCH(game, hipLaunchKernelGGL(k_export_dataset<G>, dim3((unsigned)((n * G::CELLS + 255) / 256)), dim3(256), 0, s,
-                                         v, (long long)first, (long long)n, planes, pol, val));
+    GAME_SWITCH(game, {
+        constexpr int PER = G::CELLS > G::A ? G::CELLS : G::A;
+        hipLaunchKernelGGL(k_export_dataset<G>, dim3((unsigned)((n * PER + 255) / 256)), dim3(256), 0, s, v,
+                           (long long)first, (long long)n, planes, pol, val);
+    });
 }
 
 }  // namespace azsp

@@ -34,7 +34,10 @@ typedef struct azsp_engine azsp_engine;
 /* Game plugin ids: device-side traits standing in for BaseGame subclasses
  * (src/alphazero_simple/base_game.py:6-62). */
 enum { AZSP_GAME_CONNECT4 = 0,   /* src/alphazero_simple/connect4_game.py:6-101 */
-       AZSP_GAME_CONNECT2 = 1 }; /* src/alphazero_simple/connect2_game.py:6-80  */
+       AZSP_GAME_CONNECT2 = 1,   /* src/alphazero_simple/connect2_game.py:6-80  */
+       AZSP_GAME_GOMOKU9  = 2 }; /* 9x9, five in a row: NOT in the reference -- device side of the new BaseGame plugin
+                                    alphazero-implementation_amd/azsp/games.py GomokuGame (BASELINE.json configs[4]);
+                                    hash / host evaluators only (no device network yet)                          */
 
 /* Evaluator kinds: what stands behind BaseModel.predict (src/alphazero_simple/base_model.py:52-58). */
 enum { AZSP_EVAL_RESNET = 0,  /* on-device fp32 MFMA forward of ResNet (src/alphazero_simple/resnet.py:30-157) */
@@ -108,7 +111,8 @@ const char *azsp_last_error(void);
 int  azsp_game_info(int32_t game, int32_t *rows, int32_t *cols, int32_t *n_actions, int32_t *max_plies);
 
 /* The device game trait evaluated on the HOST (the trait code in csrc/azsp_games.h is shared by host and
- * device): for a canonical board, the legal-move bit mask (get_valid_moves, connect4_game.py:48-56), the
+ * device): for a canonical board, the legal-move bit mask (get_valid_moves, connect4_game.py:48-56;
+ * int32[(A + 31) / 32] words, bit a of the mask = action a), the
  * reward for the side to move (get_reward_for_player(board, +1), :90-98; 2 = game not over) and the canonical
  * board after `action` by the side to move, seen by the opponent (get_next_state + get_canonical_board(-1),
  * :28-42,:100-101).  No GPU needed: this is what the CPU conformance test pins against the reference fixtures. */

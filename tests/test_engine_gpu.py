@@ -456,3 +456,41 @@ def test_search_options_beyond_the_reference(azsp, opts):
         assert [s.state.tolist() for s in ep.samples] == [np.asarray(s).tolist() for s, _, _ in r]
         assert [s.policy.tolist() for s in ep.samples] == [np.asarray(p).tolist() for _, p, _ in r]
         assert [s.value for s in ep.samples] == [int(z) for _, _, z in r]
+
+
+# ------------------------------------------------------------------------------------ Gomoku 9x9 (new plugin game)
+def test_gomoku_search_matches_reference_algorithm_fixtures(azsp):
+    """81 actions per node (64 lanes x 2 per game), numpy's pairwise np.sum over the priors, 128-bit boards:
+    bit-exact against the reference's MCTS.run_batch run with the Gomoku plugin (tests/golden/gomoku_hash.json)."""
+    for run in load_json("gomoku_hash.json")["search"]:
+        boards = np.array(run["boards"], dtype=np.int8)
+        with _engine(azsp, "gomoku9", len(boards), run["sims"], hash_salt=run["salt"]) as e:
+            e.use_hash_evaluator()
+            _check_run(e.run_batch(boards), run)
+
+
+@pytest.mark.parametrize("model_cls", [HashStub, HostOnlyModel])
+def test_gomoku_generate_episodes_matches_reference_algorithm_fixtures(azsp, model_cls):
+    for run in load_json("gomoku_hash.json")["episodes"]:
+        cfg = azsp.AlphaZeroConfig(32, 1, run["sims"], run["n"], 1, 1)
+        gen = azsp.EpisodeGenerator(game=azsp.GomokuGame(), config=cfg)
+        np.random.seed(run["seed"])
+        eps = list(gen.generate_episodes(model_cls("gomoku9", run["salt"])))
+        assert float(np.random.random_sample()) == run["rng_after"]
+        _episodes_equal(eps, run["episodes"])
+
+
+@pytest.mark.parametrize("n,sims,seed,salt", [(96, 60, 5, 1), (8, 200, 6, 2)])
+def test_gomoku_generate_matches_c_oracle_at_larger_sizes(azsp, n, sims, seed, salt):
+    """BASELINE configs[4]'s search shape (200 sims, 81 actions) at oracle-sized slot counts."""
+    ref = co.generate("gomoku9", sims, n, salt, seed=seed, trace=False)
+    np.random.seed(seed)
+    gen = azsp.EpisodeGenerator(game=azsp.GomokuGame(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    eps = list(gen.generate_episodes(HashStub("gomoku9", salt)))
+    assert float(np.random.random_sample()) == ref["next_uniform"]
+    assert len(eps) == n
+    for e, ep in enumerate(eps):
+        lo, hi = ref["ep_offset"][e], ref["ep_offset"][e + 1]
+        assert np.array_equal(np.stack([s.state for s in ep.samples]).reshape(hi - lo, -1), ref["states"][lo:hi])
+        assert np.array_equal(np.stack([s.policy for s in ep.samples]), ref["policies"][lo:hi])
+        assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()

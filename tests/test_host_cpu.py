@@ -167,3 +167,46 @@ def test_device_game_traits_match_reference_on_host(fname, gid, A):
                 # reference: next = get_next_state(board, player, action); canonical for the opponent = -player * next
                 expect = (-player * np.array(c["next"], dtype=np.int64)).astype(np.int8).reshape(-1)
                 assert np.array_equal(nxt, expect)
+
+
+def test_gomoku_device_trait_matches_oracle_rules_on_host():
+    """The Gomoku9 bit-set trait (two 64-bit words per side, 5-in-a-row by shift-and) evaluated on the CPU
+    against the cell-array rules of the oracle, over random playouts and arbitrary boards."""
+    import ctypes as C
+    from oracle import az_oracle as oz
+    lib = _lib.load()
+    rules = oz.G9Rules()
+    rng = np.random.RandomState(8)
+
+    def check(board, action):
+        canon = np.asarray(board, dtype=np.int8).reshape(-1)
+        mask = (C.c_int32 * 3)()
+        term = C.c_int32()
+        nxt = np.zeros(81, np.int8)
+        assert lib.azsp_game_rules(2, canon.ctypes.data_as(C.POINTER(C.c_int8)), int(action),
+                                   nxt.ctypes.data_as(C.POINTER(C.c_int8)), mask, C.byref(term)) == 0
+        assert [(mask[a >> 5] >> (a & 31)) & 1 for a in range(81)] == rules.valid_moves(board)
+        rew = rules.reward(board, 1)
+        assert term.value == (2 if rew is None else rew)
+        nb, _ = rules.next_state(board, 1, action)
+        assert np.array_equal(nxt.reshape(9, 9), -nb)
+
+    for _ in range(40):
+        b, p = rules.init_board(), 1
+        for _ in range(81):
+            legal = [i for i, v in enumerate(rules.valid_moves(b)) if v]
+            a = int(rng.choice(legal))
+            check(rules.canonical(b, p), a)
+            b, p = rules.next_state(b, p, a)
+            if rules.reward(b, p) is not None:
+                check(rules.canonical(b, p), int(rng.randint(81)))
+                break
+    for _ in range(200):
+        check(rng.randint(-1, 2, size=(9, 9)), int(rng.randint(81)))
+    lines = np.zeros((9, 9), dtype=int)
+    lines[4, 2:7] = 1                                   # exactly five across the 64-bit word boundary rows
+    check(lines, 0)
+    lines = np.zeros((9, 9), dtype=int)
+    for i in range(5):
+        lines[4 + i, 8 - i] = -1                        # anti-diagonal reaching the last row
+    check(lines, 0)
