@@ -62,11 +62,12 @@ def configure_engine_for_model(engine: Engine, model) -> None:
 
 def engine_geometry_for_model(model, game=None) -> tuple[int, int, int]:
     """(res_blocks, channels, hash_salt) to create an engine for this model.  The device network exists for
-    Connect-4 only (as the reference's ResNet.predict, resnet.py:135); other games evaluate through the host callback."""
+    Connect-4 (the reference's ResNet, resnet.py:30-157) and, with the same architecture, for the 9x9 Gomoku plugin;
+    other games evaluate through the host callback."""
     if hasattr(model, "azsp_hash_salt"):
         return 0, 0, int(model.azsp_hash_salt)
     sd = model.state_dict() if hasattr(model, "state_dict") else None
-    if game is not None and game_id_of(game) != 0:
+    if game is not None and game_id_of(game) not in (0, 2):
         return 0, 0, 0
     if sd is not None and is_resnet_state_dict(sd):
         _, blocks, ch = resnet_blob(sd)

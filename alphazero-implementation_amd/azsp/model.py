@@ -131,12 +131,16 @@ class ResNet(BaseModel):
 
     def predict(self, boards: list[np.ndarray]) -> tuple[list[np.ndarray], list[float]]:
         """boards -> (list of float32[A] move probabilities, list of float32 values); masked softmax
-        over legal columns and tanh as in the reference, computed by the fused gfx950 kernel."""
+        over the game's legal moves (Connect-4: columns whose top cell is empty, as the reference; Gomoku: empty
+        cells) and tanh, computed by the fused gfx950 kernel."""
         from .engine import Engine           # late import: training-only users never load the .so
         from .weights import resnet_blob
         if self._azsp_engine is None:
             dev = int(os.environ.get("AZSP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-            self._azsp_engine = Engine("connect4", 4096, 1, device=dev, res_blocks=self.num_res_blocks,
+            trait = {(6, 7, 7): "connect4", (9, 9, 81): "gomoku9"}.get((self.rows, self.cols, self.action_size))
+            if trait is None:
+                raise NotImplementedError(f"no device network for a {self.rows}x{self.cols} board with {self.action_size} actions")
+            self._azsp_engine = Engine(trait, 4096, 1, device=dev, res_blocks=self.num_res_blocks,
                                        channels=self.num_channels,
                                        f16_split=os.environ.get("AZSP_F16_SPLIT", "0") == "1")
         fp = self._fingerprint()

@@ -47,10 +47,17 @@ template <int W>
 AZ_HD void board_store(u64 *arr, size_t idx, const Board<W> &b) {
     for (int i = 0; i < W; ++i) arr[idx * W + i] = b.w[i];
 }
+// (selects instead of runtime-indexed words: a dynamically indexed register array would go to scratch)
 template <int W>
-AZ_HD bool board_bit(const Board<W> &b, int bit) { return (b.w[bit >> 6] >> (bit & 63)) & 1ull; }
+AZ_HD bool board_bit(const Board<W> &b, int bit) {
+    u64 x = b.w[0];
+    for (int k = 1; k < W; ++k) x = (bit >> 6) == k ? b.w[k] : x;
+    return (x >> (bit & 63)) & 1ull;
+}
 template <int W>
-AZ_HD void board_set(Board<W> &b, int bit) { b.w[bit >> 6] |= 1ull << (bit & 63); }
+AZ_HD void board_set(Board<W> &b, int bit) {
+    for (int k = 0; k < W; ++k) b.w[k] |= (bit >> 6) == k ? 1ull << (bit & 63) : 0ull;
+}
 
 // --------------------------------------------------------------------------------------------
 // Connect-4, 6x7, four in a row.  src/alphazero_simple/connect4_game.py:6-101

@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
 struct NetGeom {
-    int rows, cols, cells, A;
+    int rows, cols, cells, A, AP;
     int C, Cp, NT, S;          // channels, padded to 32, column tiles, k-steps per tap (Cp/2)
     int blocks, TB;            // residual blocks, boards per workgroup
 };
@@ -172,8 +172,9 @@ __global__ __launch_bounds__(256 * CW, (CW == 1 && MT == 1 && NT <= 2 ? 3 : 2)) 
     constexpr int ZERO_IDX = WG_ROWS * STRIDE;
     extern __shared__ float smem[];
     float *act = smem;                             // [WG_ROWS + 1][STRIDE]
-    float *part = smem + (WG_ROWS + 1) * STRIDE;   // [WG_ROWS][8] FC partial sums, then [TB][8] logits
-    float *hval = part + WG_ROWS * 8 + TB * 8;     // [WG_ROWS][4] value-head activations
+    constexpr int AP = G::AP;                      // actions padded to a multiple of 8
+    float *part = smem + (WG_ROWS + 1) * STRIDE;   // [WG_ROWS][8] FC partial sums, then [TB][AP] logits
+    float *hval = part + WG_ROWS * 8 + TB * AP;    // [WG_ROWS][4] value-head activations
 
     const int n_leaf = *n_leaf_p;
     const int board0 = blockIdx.x * TB;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256 * CW, (CW == 1 && MT == 1 && NT <= 2 ? 3 : 2)) 
     // ---- per-lane row geometry -------------------------------------------------------------------
     int ridx[MT];
     uint32_t vmask[MT];
-    u64 bm[MT], bt[MT];
+    typename G::B bm[MT], bt[MT];
     int ry[MT], rx[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -205,12 +206,12 @@ __global__ __launch_bounds__(256 * CW, (CW == 1 && MT == 1 && NT <= 2 ? 3 : 2)) 
         ridx[mt] = r * STRIDE + half;
         ry[mt] = y;
         rx[mt] = x;
-        bm[mt] = 0;
-        bt[mt] = 0;
+        bm[mt] = board_zero<G::W>();
+        bt[mt] = board_zero<G::W>();
         if (real) {
             const int slot = leaf_slot[board0 + b];
-            bm[mt] = mine[slot];
-            bt[mt] = theirs[slot];
+            bm[mt] = board_load<G::W>(mine, slot);
+            bt[mt] = board_load<G::W>(theirs, slot);
         }
     }
 
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256 * CW, (CW == 1 && MT == 1 && NT <= 2 ? 3 : 2)) 
                 if (kk < 27 && ((vmask[mt] >> tap) & 1u)) {
                     const int yy = ry[mt] + tap / 3 - 1, xx = rx[mt] + tap % 3 - 1;
                     const int bit = G::bit_of(yy, xx);
-                    const int mi = (int)((bm[mt] >> bit) & 1ull), th = (int)((bt[mt] >> bit) & 1ull);
+                    const int mi = board_bit(bm[mt], bit) ? 1 : 0, th = board_bit(bt[mt], bit) ? 1 : 0;
                     const int on = plane == 0 ? (1 - mi) * (1 - th) : (plane == 1 ? mi : th);
                     val = (float)on;
                 }
@@ -343,50 +344,80 @@ __global__ __launch_bounds__(256 * CW, (CW == 1 && MT == 1 && NT <= 2 ? 3 : 2)) 
     __syncthreads();
 
     // ---- Linear layers: Flatten is (c, y, x) order (resnet.py:60-61, :69-70) -------------------------
-    // thread r (< TB*CELLS) = one board cell: partial dot products over channels, fixed order
-    if (tid < TB * CELLS) {
-        const int pos = tid % CELLS;
-        float pa[8];
+    float *logits = part + WG_ROWS * 8;            // [TB][AP]; value logit of board b at vlogit[b]
+    float *vlogit = logits + TB * AP - 0;          // (for A <= 7 the value logit lives in logits[b][7])
+    if constexpr (A <= 7) {
+        // thread r (< TB*CELLS) = one board cell: partial dot products over channels, fixed order
+        if (tid < TB * CELLS) {
+            const int pos = tid % CELLS;
+            float pa[8];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) pa[o] = 0.0f;
-        const float *hrow = act + tid * STRIDE;
-        for (int c = 0; c < POL_CH; ++c) {
-            const float h = hrow[c];
-            const float4 w0 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8);
-            const float4 w1 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8 + 4);
-            pa[0] = fmaf(h, w0.x, pa[0]); pa[1] = fmaf(h, w0.y, pa[1]); pa[2] = fmaf(h, w0.z, pa[2]); pa[3] = fmaf(h, w0.w, pa[3]);
-            pa[4] = fmaf(h, w1.x, pa[4]); pa[5] = fmaf(h, w1.y, pa[5]); pa[6] = fmaf(h, w1.z, pa[6]);
+            for (int o = 0; o < 8; ++o) pa[o] = 0.0f;
+            const float *hrow = act + tid * STRIDE;
+            for (int c = 0; c < POL_CH; ++c) {
+                const float h = hrow[c];
+                const float4 w0 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8);
+                const float4 w1 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8 + 4);
+                pa[0] = fmaf(h, w0.x, pa[0]); pa[1] = fmaf(h, w0.y, pa[1]); pa[2] = fmaf(h, w0.z, pa[2]); pa[3] = fmaf(h, w0.w, pa[3]);
+                pa[4] = fmaf(h, w1.x, pa[4]); pa[5] = fmaf(h, w1.y, pa[5]); pa[6] = fmaf(h, w1.z, pa[6]);
+            }
+            float pv = 0.0f;
+#pragma unroll
+            for (int c = 0; c < VAL_CH; ++c) pv = fmaf(hval[tid * 4 + c], P.fcv_w[c * CELLS + pos], pv);
+            pa[7] = pv;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) part[tid * 8 + o] = pa[o];
         }
-        float pv = 0.0f;
-#pragma unroll
-        for (int c = 0; c < VAL_CH; ++c) pv = fmaf(hval[tid * 4 + c], P.fcv_w[c * CELLS + pos], pv);
-        pa[7] = pv;
-#pragma unroll
-        for (int o = 0; o < 8; ++o) part[tid * 8 + o] = pa[o];
+        __syncthreads();
+        if (tid < TB * 8) {
+            const int b = tid >> 3, o = tid & 7;
+            float sum = 0.0f;
+            for (int pos = 0; pos < CELLS; ++pos) sum += part[(b * CELLS + pos) * 8 + o];
+            logits[tid] = sum + (o < 7 ? (o < A ? P.fcp_b[o] : 0.0f) : P.fcv_b[0]);
+        }
+        vlogit = nullptr;
+    } else {
+        // wide action spaces (Gomoku: 81): one thread per (board, action) walks the 32 x CELLS inputs in
+        // flatten order; weights are stored [input][AP] so that the threads of a board read them coalesced
+#pragma unroll 1
+        for (int t = tid; t < TB * (A + 1); t += 256 * CW) {
+            const int b = t / (A + 1), o = t % (A + 1);
+            float sum = 0.0f;
+            if (o < A) {
+#pragma unroll 1
+                for (int c = 0; c < POL_CH; ++c)
+#pragma unroll 3
+                    for (int pos = 0; pos < CELLS; ++pos)
+                        sum = fmaf(act[(b * CELLS + pos) * STRIDE + c], P.fcp_w[((size_t)c * CELLS + pos) * AP + o], sum);
+                logits[b * AP + o] = sum + P.fcp_b[o];
+            } else {
+#pragma unroll 1
+                for (int c = 0; c < VAL_CH; ++c)
+#pragma unroll 1
+                    for (int pos = 0; pos < CELLS; ++pos)
+                        sum = fmaf(hval[(b * CELLS + pos) * 4 + c], P.fcv_w[c * CELLS + pos], sum);
+                part[b] = sum + P.fcv_b[0];
+            }
+        }
+        vlogit = part;
     }
     __syncthreads();
-    float *logits = part + WG_ROWS * 8;            // [TB][8]
-    if (tid < TB * 8) {
-        const int b = tid >> 3, o = tid & 7;
-        float sum = 0.0f;
-        for (int pos = 0; pos < CELLS; ++pos) sum += part[(b * CELLS + pos) * 8 + o];
-        logits[tid] = sum + (o < 7 ? (o < A ? P.fcp_b[o] : 0.0f) : P.fcv_b[0]);
-    }
-    __syncthreads();
-    // ---- masked softmax + tanh (ResNet.predict resnet.py:143-151) -----------------------------------
+    // ---- masked softmax + tanh (ResNet.predict resnet.py:143-151; legal = the game's valid moves) --------
     if (tid < TB && board0 + tid < n_leaf) {
         const int j = board0 + tid;
         const int slot = leaf_slot[j];
-        const uint32_t legal = G::legal_mask(mine[slot], theirs[slot]);
+        const typename G::B bmine = board_load<G::W>(mine, slot), btheirs = board_load<G::W>(theirs, slot);
+        const float *lg = logits + tid * AP;
         float mx = -INFINITY;
-#pragma unroll
-        for (int a = 0; a < A; ++a) if ((legal >> a) & 1u) mx = fmaxf(mx, logits[tid * 8 + a]);
-        float ex[A], den = 0.0f;
-#pragma unroll
-        for (int a = 0; a < A; ++a) { ex[a] = ((legal >> a) & 1u) ? expf(logits[tid * 8 + a] - mx) : 0.0f; den += ex[a]; }
-#pragma unroll
-        for (int a = 0; a < PSTRIDE; ++a) out_p[(size_t)j * PSTRIDE + a] = a < A ? ex[a < A ? a : 0] / den : 0.0f;
-        out_v[j] = tanhf(logits[tid * 8 + 7]);
+#pragma unroll 1
+        for (int a = 0; a < A; ++a) if (G::legal(bmine, btheirs, a)) mx = fmaxf(mx, lg[a]);
+        float den = 0.0f;
+#pragma unroll 1
+        for (int a = 0; a < A; ++a) den += G::legal(bmine, btheirs, a) ? expf(lg[a] - mx) : 0.0f;
+#pragma unroll 1
+        for (int a = 0; a < AP; ++a)
+            out_p[(size_t)j * AP + a] = (a < A && G::legal(bmine, btheirs, a)) ? expf(lg[a] - mx) / den : 0.0f;
+        out_v[j] = tanhf(vlogit ? vlogit[tid] : lg[7]);
     }
 }
 
@@ -395,7 +426,9 @@ __global__ __launch_bounds__(256 * CW, (CW == 1 && MT == 1 && NT <= 2 ? 3 : 2)) 
 // ------------------------------------------------------------------------------------------------
 static bool geom_for(int game, int blocks, int channels, NetGeom &g) {
     // The reference network is Connect-4 only (ResNet.predict hard-codes Connect4Game, resnet.py:135).
-    if (game == 0) { g.rows = Connect4::ROWS; g.cols = Connect4::COLS; g.cells = Connect4::CELLS; g.A = Connect4::A; }
+    if (game == 0) { g.rows = Connect4::ROWS; g.cols = Connect4::COLS; g.cells = Connect4::CELLS; g.A = Connect4::A; g.AP = Connect4::AP; }
+    // Gomoku 9x9 (not a reference network: the same architecture on the plugin game, legal = empty cells)
+    else if (game == 2) { g.rows = Gomoku9::ROWS; g.cols = Gomoku9::COLS; g.cells = Gomoku9::CELLS; g.A = Gomoku9::A; g.AP = Gomoku9::AP; }
     else return false;
     if (blocks < 0 || channels <= 0) return false;
     g.C = channels;
@@ -451,8 +484,8 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
     n->o_pol_b = reserve(32);
     n->o_val_w = reserve((size_t)9 * g.Cp * 4);
     n->o_val_b = reserve(32);
-    n->o_fcp_w = reserve((size_t)POL_CH * g.cells * 8);
-    n->o_fcp_b = reserve(8);
+    n->o_fcp_w = reserve((size_t)POL_CH * g.cells * g.AP);
+    n->o_fcp_b = reserve(g.AP);
     n->o_fcv_w = reserve((size_t)VAL_CH * g.cells);
     n->o_fcv_b = reserve(4);
     off += 8 * 64 * 4;                      // slack for the one-block weight prefetch past the last array
@@ -512,7 +545,7 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
         for (int c2 = 0; c2 < POL_CH; ++c2)
             for (int pos = 0; pos < g.cells; ++pos)
                 for (int o = 0; o < g.A; ++o)
-                    host[n->o_fcp_w + ((size_t)c2 * g.cells + pos) * 8 + o] = fw[(size_t)o * POL_CH * g.cells + (size_t)c2 * g.cells + pos];
+                    host[n->o_fcp_w + ((size_t)c2 * g.cells + pos) * g.AP + o] = fw[(size_t)o * POL_CH * g.cells + (size_t)c2 * g.cells + pos];
         for (int o = 0; o < g.A; ++o) host[n->o_fcp_b + o] = fb[o];
     }
     {
@@ -540,7 +573,7 @@ static void launch_forward(const NetParams &P, const u64 *mine, const u64 *their
     constexpr int WG_ROWS = 128 * MT;
     constexpr int TB = WG_ROWS / G::CELLS;
     constexpr int STRIDE = 32 * NT + 1;
-    const size_t lds = ((size_t)(WG_ROWS + 1) * STRIDE + WG_ROWS * 8 + TB * 8 + WG_ROWS * 4) * sizeof(float);
+    const size_t lds = ((size_t)(WG_ROWS + 1) * STRIDE + WG_ROWS * 8 + TB * G::AP + WG_ROWS * 4) * sizeof(float);
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -567,7 +600,12 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
     P.conv_w_stride = (int)n->conv_w_stride;
     P.conv_b_stride = (int)n->conv_b_stride;
     P.blocks = n->g.blocks;
-    (void)game;
+    if (game == 2) {       // Gomoku 9x9: 3 boards (243 rows) per workgroup up to 64 channels, 1 board (81 of 128 rows) above
+#define FWG(NTV, MTV, PFV) launch_forward<Gomoku9, NTV, MTV, PFV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
+        if (n->g.NT == 1) FWG(1, 2, 0); else if (n->g.NT == 2) FWG(2, 2, 0); else if (n->g.NT == 3) FWG(3, 1, 1); else FWG(4, 1, 1);
+#undef FWG
+        return;
+    }
     // rows per workgroup: 2 row tiles per wave (6 boards / WG) by default; AZSP_RESNET_MT=1 selects
     // 1 row tile per wave (3 boards / WG, more workgroups per CU) -- same results, tuning knob only
     // small batches are latency-bound (one workgroup's serial MFMA chain): halve the rows per workgroup

@@ -494,3 +494,49 @@ def test_gomoku_generate_matches_c_oracle_at_larger_sizes(azsp, n, sims, seed, s
         assert np.array_equal(np.stack([s.state for s in ep.samples]).reshape(hi - lo, -1), ref["states"][lo:hi])
         assert np.array_equal(np.stack([s.policy for s in ep.samples]), ref["policies"][lo:hi])
         assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()
+
+
+@pytest.mark.parametrize("blocks,ch", [(2, 32), (3, 64), (2, 128)])
+def test_gomoku_resnet_predict_on_device(azsp, blocks, ch):
+    """The same ResNet architecture on the 9x9 plugin game (policy Linear 32*81 -> 81, legal = empty cells).
+    The reference's ResNet.predict cannot mask a 9x9 board, so the check is against this module's own PyTorch
+    forward on the CPU (tolerance 1e-5) -- parity is not pinnable by the reference here."""
+    import torch
+    torch.manual_seed(7 * blocks + ch)
+    net = azsp.ResNet((9, 9), 81, blocks, ch)
+    net.eval()
+    rules = oz.G9Rules()
+    boards = random_midgame_boards(rules, np.random.RandomState(3), 10, 60)
+    p, v = net.predict(boards)
+    with torch.no_grad():
+        logits, vl = net.forward(net._states_to_tensor(boards))
+        mask = torch.tensor([rules.valid_moves(b) for b in boards])
+        pt = torch.softmax(logits.masked_fill(mask == 0, float("-inf")), dim=1).numpy()
+        vt = torch.tanh(vl).numpy()
+    assert np.stack(p).shape == (10, 81)
+    assert np.max(np.abs(np.stack(p) - pt)) < 1e-5 and np.max(np.abs(np.array(v) - vt)) < 1e-5
+    assert np.all(np.stack(p)[mask.numpy() == 0] == 0)
+
+
+def test_gomoku_self_play_with_device_network_bit_exact_vs_oracle(azsp):
+    """End-to-end Gomoku self-play with the device network: the C oracle asks the same kernel for (P, V)."""
+    import torch
+    from azsp.engine import Engine
+    from azsp.weights import resnet_blob
+    torch.manual_seed(5)
+    net = azsp.ResNet((9, 9), 81, 2, 32)
+    blob, blocks, ch = resnet_blob(net)
+    n, sims, seed = 6, 30, 4
+    with Engine("gomoku9", 64, 1, res_blocks=blocks, channels=ch) as pe:
+        pe.load_resnet(blob)
+        cb = co.make_predict_cb(lambda bs: pe.predict(np.stack(bs)), (9, 9), 81)
+        ref = co.generate("gomoku9", sims, n, seed=seed, predict_cb=cb, trace=False)
+    np.random.seed(seed)
+    gen = azsp.EpisodeGenerator(game=azsp.GomokuGame(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    eps = list(gen.generate_episodes(net))
+    assert float(np.random.random_sample()) == ref["next_uniform"]
+    for e, ep in enumerate(eps):
+        lo, hi = ref["ep_offset"][e], ref["ep_offset"][e + 1]
+        assert np.array_equal(np.stack([s.state for s in ep.samples]).reshape(hi - lo, -1), ref["states"][lo:hi])
+        assert np.array_equal(np.stack([s.policy for s in ep.samples]), ref["policies"][lo:hi])
+        assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()
