@@ -47,14 +47,14 @@ def resnet_flops_per_board(blocks: int, ch: int, cells: int = 42, actions: int =
     return 2.0 * (conv + fc)
 
 
-def tree_report(st: dict, wall_s: float) -> dict:
+def tree_report(st: dict, wall_s: float, n_actions: int = 7) -> dict:
     """Selection/expansion/backup kernels: HBM-bound graph work.  Algorithmic bytes per
-    simulation with d levels selected and A = 7 children: select d*A*20 (N, W, P, child index per child) + leaf
+    simulation with d levels selected and A children per node: select d*A*20 (N, W, P, child index per child) + leaf
     step 32 + expand A*20 + 24 + path/backup (d + 1)*24; achieved = bytes / summed kernel time (HIP events on the
     engine streams; the kernels of one slot group run concurrently with the other groups' inference)."""
     sims = int(st["evals"] + st["terminal_leaves"])
     depth = st["path_nodes"] / max(sims, 1) - 1.0
-    bytes_per_sim = depth * 7 * 20 + 32 + (7 * 20 + 24) + (depth + 1.0) * 24
+    bytes_per_sim = depth * n_actions * 20 + 32 + (n_actions * 20 + 24) + (depth + 1.0) * 24
     k_ms = st["select_ms"] + st["expand_ms"]
     gbs = sims * bytes_per_sim / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     return {"select_ms": st["select_ms"], "expand_ms": st["expand_ms"], "play_ms": st["play_ms"],
@@ -121,7 +121,11 @@ def main() -> None:
     ap.add_argument("--precision", choices=["f32", "f16x2"], default="f32", help="inference arithmetic of the headline")
     ap.add_argument("--single", action="store_true", help="measure only --precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--game", choices=["connect4", "gomoku9"], default="connect4",
+                    help="gomoku9 = BASELINE.json configs[4]'s game (not a headline config; fp32 only, no CPU baseline)")
     args = ap.parse_args()
+    if args.game == "gomoku9":
+        args.single, args.no_cpu_baseline, args.precision = True, True, "f32"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -148,11 +152,12 @@ def main() -> None:
     from azsp.distributed import all_gather_records
 
     torch.manual_seed(0)                       # same random-weight net on every rank
-    net = azsp.ResNet((6, 7), 7, args.blocks, args.channels)
+    game_cls, board, n_act = (azsp.Connect4Game, (6, 7), 7) if args.game == "connect4" else (azsp.GomokuGame, (9, 9), 81)
+    net = azsp.ResNet(board, n_act, args.blocks, args.channels)
     net.eval()
     cfg = azsp.AlphaZeroConfig(batch_size=32, num_iterations=1, num_simulations=args.sims, num_episodes=args.slots,
                                num_iters_for_train_history=1, epochs=1)
-    fpb = resnet_flops_per_board(args.blocks, args.channels)
+    fpb = resnet_flops_per_board(args.blocks, args.channels, board[0] * board[1], n_act)
 
     def fence():
         if dist is not None:
@@ -160,7 +165,7 @@ def main() -> None:
         torch.cuda.synchronize()
 
     def measure(precision: str) -> dict:
-        gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg, device=local_rank, timing=True,
+        gen = azsp.EpisodeGenerator(game=game_cls(), config=cfg, device=local_rank, timing=True,
                                     n_groups=args.groups, f16_split=precision == "f16x2")
 
         def step(seed: int):
@@ -211,7 +216,7 @@ def main() -> None:
                          "boards_per_launch": st["infer_boards"] / launches, "avg_launch_ms": avg_ms, "launches": launches,
                          "concurrent_launches": overlap, "busy_ms": union_ms,
                          "infer_share_of_wall": union_ms * 1e-3 / dt if dt > 0 else None},
-            "tree": tree_report(st, dt),
+            "tree": tree_report(st, dt, n_act),
         }
 
     head = measure(args.precision)
@@ -221,12 +226,12 @@ def main() -> None:
 
     if rank == 0:
         out = {
-            "metric": "self-play episodes/sec (Connect-4, 100 sims/move)" if args.sims == 100 else
-                      f"self-play episodes/sec (Connect-4, {args.sims} sims/move)",
+            "metric": "self-play episodes/sec (Connect-4, 100 sims/move)" if (args.sims == 100 and args.game == "connect4") else
+                      f"self-play episodes/sec ({args.game}, {args.sims} sims/move)",
             "value": head["value"], "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": head["dtype"], "data": "synthetic (empty-board starts, random-weight net, seeded RNG)",
-            "config": {"workload": f"Connect-4 self-play, ResNet {args.channels}ch/{args.blocks}blk random weights, "
+            "config": {"workload": f"{args.game} self-play, ResNet {args.channels}ch/{args.blocks}blk random weights, "
                                    f"{args.sims} sims/move, {args.slots} concurrent games per GPU, first "
                                    f"{args.slots} completions per GPU per step",
                        "slots_per_gpu": args.slots, "sims": args.sims, "parallelism": f"game-sharded x{world}",
