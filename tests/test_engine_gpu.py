@@ -540,3 +540,44 @@ def test_gomoku_self_play_with_device_network_bit_exact_vs_oracle(azsp):
         assert np.array_equal(np.stack([s.state for s in ep.samples]).reshape(hi - lo, -1), ref["states"][lo:hi])
         assert np.array_equal(np.stack([s.policy for s in ep.samples]), ref["policies"][lo:hi])
         assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()
+
+
+def test_background_thread_generation_next_to_torch_training(azsp):
+    """The reference can run generation on a daemon thread while Lightning trains
+    (src/alphazero_less_simple/core/training/datamodule.py:19-47,111-117).  The engine uses private non-blocking
+    HIP streams and ctypes releases the GIL, so generation on a second thread, concurrent with PyTorch work on the
+    default stream, must give exactly the single-threaded result."""
+    import threading
+    import torch
+    n, sims, seed, salt = 1024, 60, 17, 5
+    ref = co.generate("connect4", sims, n, salt, seed=seed, trace=False)
+    net = torch.nn.Sequential(torch.nn.Linear(512, 512), torch.nn.ReLU(), torch.nn.Linear(512, 512)).cuda()
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    net(torch.randn(8, 512, device="cuda")).sum().backward()       # warm the torch side up before the race
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    out, err = [], []
+
+    def worker():
+        try:
+            np.random.seed(seed)                    # the generator is the only consumer of the global RNG here
+            out.extend(gen.generate_episodes(HashStub("connect4", salt)))
+        except BaseException as exc:                # noqa: BLE001
+            err.append(exc)
+
+    th = threading.Thread(target=worker, daemon=True)
+    th.start()
+    steps = 0
+    while th.is_alive() and steps < 20000:          # "training" on the default stream meanwhile
+        x = torch.randn(256, 512, device="cuda")
+        loss = net(x).square().mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        steps += 1
+    th.join(timeout=120)
+    assert not err and not th.is_alive() and steps > 0
+    assert len(out) == n
+    for e, ep in enumerate(out):
+        lo, hi = ref["ep_offset"][e], ref["ep_offset"][e + 1]
+        assert np.array_equal(np.stack([s.state for s in ep.samples]).reshape(hi - lo, -1), ref["states"][lo:hi])
+        assert np.array_equal(np.stack([s.policy for s in ep.samples]), ref["policies"][lo:hi])
