@@ -71,7 +71,7 @@ def engine_geometry_for_model(model, game=None) -> tuple[int, int, int]:
         return 0, 0, 0
     if sd is not None and is_resnet_state_dict(sd):
         _, blocks, ch = resnet_blob(sd)
-        if 1 <= (ch + 31) // 32 <= 4:
+        if 1 <= (ch + 31) // 32 <= 8:
             return blocks, ch, 0
     return 0, 0, 0
 

@@ -158,13 +158,14 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
 //   row = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5),  col = l & 31
 __device__ __forceinline__ int cd_row(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
 
-template <class G, int NT, int MT, int PF, int CW = 1>
-__global__ __launch_bounds__(256 * CW, (CW == 1 && MT == 1 && NT <= 2 ? 3 : 2)) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
+template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4>
+__global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 && NT <= 2 ? 3 : 2)) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
                                                          const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
                                                          float *__restrict__ out_p, float *__restrict__ out_v) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
-    constexpr int WG_ROWS = 128 * MT;              // 4 waves x MT row tiles of 32
+    constexpr int WG_ROWS = RW * 32 * MT;          // RW row groups x MT row tiles of 32 (x CW column groups of waves)
     constexpr int WROWS = 32 * MT;                 // rows per wave
+    constexpr int NTHREADS = 64 * RW * CW;
     constexpr int TB = WG_ROWS / CELLS;            // boards per workgroup
     constexpr int CP = 32 * NT, S = CP / 2, STRIDE = CP + 1;
     constexpr int NTW = NT / CW;                   // column tiles per wave: CW waves share a row group
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256 * CW, (CW == 1 && MT == 1 && NT <= 2 ? 3 : 2)) 
     const int wave = (tid >> 6) / CW, wc = (tid >> 6) % CW;    // row group, column group
     const int col0 = wc * NTW * 32;
 
-    for (int i = tid; i < STRIDE; i += 256 * CW) act[ZERO_IDX + i] = 0.0f;
+    for (int i = tid; i < STRIDE; i += NTHREADS) act[ZERO_IDX + i] = 0.0f;
 
     // ---- per-lane row geometry -------------------------------------------------------------------
     int ridx[MT];
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(256 * CW, (CW == 1 && MT == 1 && NT <= 2 ? 3 : 2)) 
     float *logits = part + WG_ROWS * 8;            // [TB][AP]; value logit of board b at vlogit[b]
     float *vlogit = logits + TB * AP - 0;          // (for A <= 7 the value logit lives in logits[b][7])
     if constexpr (A <= 7) {
+        static_assert(TB * CELLS <= NTHREADS, "one thread per board cell");
         // thread r (< TB*CELLS) = one board cell: partial dot products over channels, fixed order
         if (tid < TB * CELLS) {
             const int pos = tid % CELLS;
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(256 * CW, (CW == 1 && MT == 1 && NT <= 2 ? 3 : 2)) 
         // wide action spaces (Gomoku: 81): one thread per (board, action) walks the 32 x CELLS inputs in
         // flatten order; weights are stored [input][AP] so that the threads of a board read them coalesced
 #pragma unroll 1
-        for (int t = tid; t < TB * (A + 1); t += 256 * CW) {
+        for (int t = tid; t < TB * (A + 1); t += NTHREADS) {
             const int b = t / (A + 1), o = t % (A + 1);
             float sum = 0.0f;
             if (o < A) {
@@ -434,7 +436,8 @@ static bool geom_for(int game, int blocks, int channels, NetGeom &g) {
     g.C = channels;
     g.Cp = (channels + 31) / 32 * 32;
     g.NT = g.Cp / 32;
-    if (g.NT < 1 || g.NT > 4) return false;      // up to 128 channels (after padding to a multiple of 32)
+    if (g.NT == 5 || g.NT == 7) { g.NT += 1; g.Cp += 32; }       // wave grids exist for 1, 2, 3, 4, 6 and 8 column tiles
+    if (g.NT < 1 || g.NT > 8) return false;      // up to 256 channels
     g.S = g.Cp / 2;
     g.blocks = blocks;
     g.TB = 256 / g.cells;
@@ -567,23 +570,24 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
     return 0;
 }
 
-template <class G, int NT, int MT, int PF, int CW = 1>
+template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4>
 static void launch_forward(const NetParams &P, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot,
                            const int32_t *n_leaf, int max_leaves, float *out_p, float *out_v, hipStream_t s) {
-    constexpr int WG_ROWS = 128 * MT;
+    constexpr int WG_ROWS = RW * 32 * MT;
     constexpr int TB = WG_ROWS / G::CELLS;
+    static_assert(TB >= 1 && TB * G::CELLS <= 64 * RW * CW, "one thread per board cell in the head phases");
     constexpr int STRIDE = 32 * NT + 1;
     const size_t lds = ((size_t)(WG_ROWS + 1) * STRIDE + WG_ROWS * 8 + TB * G::AP + WG_ROWS * 4) * sizeof(float);
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT, MT, PF, CW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT, MT, PF, CW, RW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev] = true;
     }
     const int grid = (max_leaves + TB - 1) / TB;
-    hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW>), dim3(grid), dim3(256 * CW), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
+    hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW>), dim3(grid), dim3(64 * RW * CW), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
 }
 
 void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
@@ -602,7 +606,12 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
     P.blocks = n->g.blocks;
     if (game == 2) {       // Gomoku 9x9: 3 boards (243 rows) per workgroup up to 64 channels, 1 board (81 of 128 rows) above
 #define FWG(NTV, MTV, PFV) launch_forward<Gomoku9, NTV, MTV, PFV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
-        if (n->g.NT == 1) FWG(1, 2, 0); else if (n->g.NT == 2) FWG(2, 2, 0); else if (n->g.NT == 3) FWG(3, 1, 1); else FWG(4, 1, 1);
+        // wide nets: one board (81 rows -> 3 row tiles) per workgroup, one wave per 32-channel column tile
+        if (n->g.NT == 1) FWG(1, 2, 0); else if (n->g.NT == 2) FWG(2, 2, 0);
+        else if (n->g.NT == 3) launch_forward<Gomoku9, 3, 3, 1, 3, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+        else if (n->g.NT == 4) launch_forward<Gomoku9, 4, 3, 1, 4, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+        else if (n->g.NT == 6) launch_forward<Gomoku9, 6, 3, 1, 6, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+        else launch_forward<Gomoku9, 8, 3, 1, 8, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
 #undef FWG
         return;
     }
@@ -629,7 +638,10 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
         else { if (pf == 1) FWD(2, 2, 1); else FWD(2, 2, 0); }
     }
     else if (n->g.NT == 3) { if (pf == 0) FWD(3, 1, 0); else FWD(3, 1, 1); }
-    else { if (pf == 0) FWD(4, 1, 0); else FWD(4, 1, 1); }
+    else if (n->g.NT == 4) { if (pf == 0) FWD(4, 1, 0); else FWD(4, 1, 1); }
+    // 192 / 256 channels: 3 boards (128 rows) per workgroup, 2 row groups x NT/2 column groups of waves
+    else if (n->g.NT == 6) launch_forward<Connect4, 6, 2, 1, 3, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+    else launch_forward<Connect4, 8, 2, 1, 4, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
 #undef FWD
 }
 

@@ -200,11 +200,14 @@ def test_resnet_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp, f16):
 
 
 @pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
-@pytest.mark.parametrize("blocks,ch", [(2, 32), (1, 16), (3, 48), (2, 128), (8, 128), (1, 100), (4, 64), (2, 96)])
+@pytest.mark.parametrize("blocks,ch", [(2, 32), (1, 16), (3, 48), (2, 128), (8, 128), (1, 100), (4, 64), (2, 96), (1, 160),
+                                       (2, 192), (2, 256)])
 def test_resnet_model_predict_uses_device_kernel(azsp, blocks, ch, f16, monkeypatch):
     """azsp.ResNet.predict (HIP kernel) vs the same module's PyTorch forward on the CPU, for every
     channel-tile count the kernel is instantiated for (C padded to 32/64/128).  Tolerance 1e-5."""
     import torch
+    if f16 and ch > 128:
+        pytest.skip("the split-fp16 kernel covers up to 128 channels")
     monkeypatch.setenv("AZSP_F16_SPLIT", "1" if f16 else "0")
     torch.manual_seed(blocks * 1000 + ch)
     net = azsp.ResNet((6, 7), 7, blocks, ch)
@@ -496,7 +499,7 @@ def test_gomoku_generate_matches_c_oracle_at_larger_sizes(azsp, n, sims, seed, s
         assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()
 
 
-@pytest.mark.parametrize("blocks,ch", [(2, 32), (3, 64), (2, 128)])
+@pytest.mark.parametrize("blocks,ch", [(2, 32), (3, 64), (2, 96), (2, 128), (1, 192), (2, 256)])
 def test_gomoku_resnet_predict_on_device(azsp, blocks, ch):
     """The same ResNet architecture on the 9x9 plugin game (policy Linear 32*81 -> 81, legal = empty cells).
     The reference's ResNet.predict cannot mask a 9x9 board, so the check is against this module's own PyTorch
