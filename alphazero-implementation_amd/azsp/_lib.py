@@ -14,13 +14,15 @@ GAME_CONNECT4, GAME_CONNECT2, GAME_GOMOKU9 = 0, 1, 2
 EVAL_RESNET, EVAL_HASH, EVAL_HOST = 0, 1, 2
 FLAG_TIMING = 1
 FLAG_F16_SPLIT = 2
-ABI_VERSION = 1
+RULES_SIMPLE, RULES_GEN1 = 0, 1
+ABI_VERSION = 2
 
 
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("game", C.c_int32), ("n_slots", C.c_int32), ("n_sims", C.c_int32),
                 ("device", C.c_int32), ("res_blocks", C.c_int32), ("channels", C.c_int32), ("flags", C.c_uint32),
-                ("hash_salt", C.c_uint64), ("n_groups", C.c_int32), ("arena_episodes", C.c_int32)]
+                ("hash_salt", C.c_uint64), ("n_groups", C.c_int32), ("arena_episodes", C.c_int32),
+                ("search_rules", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PlyResult(C.Structure):
@@ -38,7 +40,8 @@ class Stats(C.Structure):
 
 
 class SearchOptions(C.Structure):
-    _fields_ = [("struct_size", C.c_uint32), ("sampling_plies", C.c_int32), ("noise_eps", C.c_double)]
+    _fields_ = [("struct_size", C.c_uint32), ("sampling_plies", C.c_int32), ("noise_eps", C.c_double),
+                ("c_init", C.c_double), ("c_base", C.c_double)]
 
 
 PREDICT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int8), C.c_int32, C.POINTER(C.c_float),
@@ -60,6 +63,9 @@ SIGNATURES = {
     "azsp_run_batch": (C.c_int, [C.c_void_p, _P(C.c_int8), C.c_int32, _P(C.c_int32), _P(C.c_float), _P(C.c_double),
                                  _P(C.c_float), _P(C.c_int32)]),
     "azsp_reset": (C.c_int, [C.c_void_p]),
+    "azsp_root_values": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_double), _P(C.c_double), _P(C.c_int32)]),
+    "azsp_set_initial_board": (C.c_int, [C.c_void_p, _P(C.c_int8)]),
+    "azsp_fetch_moves": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _P(C.c_int32), C.c_int64]),
     "azsp_search": (C.c_int, [C.c_void_p]),
     "azsp_root_counts": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "azsp_set_search_options": (C.c_int, [C.c_void_p, _P(SearchOptions)]),

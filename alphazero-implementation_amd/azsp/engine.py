@@ -29,7 +29,8 @@ def _ptr(a: np.ndarray | None, ty):
 
 class Engine:
     def __init__(self, game, n_slots: int, n_sims: int, *, device: int = 0, res_blocks: int = 0, channels: int = 0,
-                 timing: bool = False, hash_salt: int = 0, n_groups: int = 0, f16_split: bool = False, arena_episodes: int = 0):
+                 timing: bool = False, hash_salt: int = 0, n_groups: int = 0, f16_split: bool = False, arena_episodes: int = 0,
+                 search_rules: int = L.RULES_SIMPLE):
         self.lib = L.load()
         self.game_id = game_id_of(game)
         r, c, a, mp = (C.c_int32() for _ in range(4))
@@ -40,7 +41,9 @@ class Engine:
         self.n_slots, self.n_sims = int(n_slots), int(n_sims)
         self.res_blocks, self.channels = int(res_blocks), int(channels)
         cfg = L.Config(C.sizeof(L.Config), self.game_id, self.n_slots, self.n_sims, int(device), self.res_blocks,
-                       self.channels, (L.FLAG_TIMING if timing else 0) | (L.FLAG_F16_SPLIT if f16_split else 0), int(hash_salt) & (2**64 - 1), int(n_groups), int(arena_episodes))
+                       self.channels, (L.FLAG_TIMING if timing else 0) | (L.FLAG_F16_SPLIT if f16_split else 0), int(hash_salt) & (2**64 - 1), int(n_groups), int(arena_episodes),
+                       int(search_rules), 0)
+        self.search_rules = int(search_rules)
         h = C.c_void_p()
         L.check(self.lib.azsp_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -129,9 +132,29 @@ class Engine:
     def search(self) -> None:
         self._check(self.lib.azsp_search(self._h))
 
-    def set_search_options(self, sampling_plies: int = -1, noise_eps: float = 0.0) -> None:
-        o = L.SearchOptions(C.sizeof(L.SearchOptions), int(sampling_plies), float(noise_eps))
+    def set_search_options(self, sampling_plies: int = -1, noise_eps: float = 0.0, c_init: float = 1.0,
+                           c_base: float = 0.0) -> None:
+        o = L.SearchOptions(C.sizeof(L.SearchOptions), int(sampling_plies), float(noise_eps), float(c_init), float(c_base))
         self._check(self.lib.azsp_set_search_options(self._h, C.byref(o)))
+
+    def root_values(self, n: int | None = None) -> dict[str, np.ndarray]:
+        """value_sum (float64) and visit_count of the first n trees of the search just run."""
+        n = self.n_slots if n is None else int(n)
+        out = {"child_w": np.empty((n, self.n_actions), np.float64), "root_w": np.empty(n, np.float64),
+               "root_n": np.empty(n, np.int32)}
+        self._check(self.lib.azsp_root_values(self._h, n, _ptr(out["child_w"], C.c_double), _ptr(out["root_w"], C.c_double),
+                                              _ptr(out["root_n"], C.c_int32)))
+        return out
+
+    def set_initial_board(self, board=None) -> None:
+        """Canonical position every game starts from (None = empty board); applies from the next reset()."""
+        b = None if board is None else self._boards_i8([board])
+        self._check(self.lib.azsp_set_initial_board(self._h, _ptr(b, C.c_int8)))
+
+    def fetch_moves(self, first: int, n: int, n_samples: int) -> np.ndarray:
+        out = np.empty(max(int(n_samples), 1), np.int32)
+        self._check(self.lib.azsp_fetch_moves(self._h, int(first), int(n), _ptr(out, C.c_int32), out.size))
+        return out[:n_samples]
 
     def search_with_noise(self, noise: np.ndarray) -> None:
         z = np.ascontiguousarray(noise, dtype=np.float64)

@@ -21,7 +21,8 @@ from .mcts import configure_engine_for_model, default_device, engine_geometry_fo
 class EpisodeGenerator:
     def __init__(self, *, game, config: AlphaZeroConfig, device: int | None = None, timing: bool = False,
                  n_groups: int = 0, f16_split: bool = False, sampling_plies: int | None = None,
-                 dirichlet_alpha: float | None = None, dirichlet_eps: float = 0.25):
+                 dirichlet_alpha: float | None = None, dirichlet_eps: float = 0.25, c_init: float = 1.0,
+                 c_base: float = 0.0):
         self.game = game
         self.config = config
         self.device = device
@@ -30,6 +31,8 @@ class EpisodeGenerator:
         # `sampling_plies` plies; gamma(alpha) root noise mixed in with weight `dirichlet_eps`, drawn per ply from
         # the global numpy RNG BEFORE the ply's uniforms (n_slots x n_actions values)
         self.sampling_plies, self.dirichlet_alpha, self.dirichlet_eps = sampling_plies, dirichlet_alpha, dirichlet_eps
+        # exploration factor c(N) in front of P*sqrt(N)/(n+1): constant c_init, or log((N+c_base+1)/c_base)+c_init
+        self.c_init, self.c_base = c_init, c_base
         self.f16_split = f16_split    # device ResNet on the fp16 matrix pipe with split operands (fp32-class accuracy)
         self.n_groups = n_groups      # concurrent slot groups (HIP streams); 0 = automatic; never changes results
         self._engine: Engine | None = None
@@ -56,7 +59,7 @@ class EpisodeGenerator:
         shape = eng.board_shape
         eng.reset()
         eng.set_search_options(-1 if self.sampling_plies is None else self.sampling_plies,
-                               self.dirichlet_eps if self.dirichlet_alpha else 0.0)
+                               self.dirichlet_eps if self.dirichlet_alpha else 0.0, self.c_init, self.c_base)
 
         def search():
             if self.dirichlet_alpha:

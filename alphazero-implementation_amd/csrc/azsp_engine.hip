@@ -88,6 +88,9 @@ struct azsp_engine {
     float *d_st_w = nullptr, *d_st_rw = nullptr;
     double *d_st_prior = nullptr;
     double *d_noise = nullptr;        // root exploration noise staging
+    double *d_st_wd = nullptr, *d_st_rwd = nullptr;   // float64 root statistics staging
+    double *d_sqrt = nullptr, *d_ctab = nullptr, *d_expl = nullptr;   // [n_sims + 2] exploration tables
+    double c_init = 1.0, c_base = 0.0;
     std::vector<int8_t> h_cells;
     std::vector<float> h_p, h_v, h_p8;
     std::vector<u64> h_mine, h_theirs;
@@ -236,7 +239,9 @@ static int search(azsp_engine *e, int n_act) {
         if (rc) return rc;
         launch_expand(game, gv[k], st);
     }
-    for (int s = 0; s < e->cfg.n_sims; ++s) {
+    // rule set 1: the root expansion above was simulation 1 (search.py:66-91)
+    const int descents = e->cfg.search_rules == AZSP_RULES_GEN1 ? e->cfg.n_sims - 1 : e->cfg.n_sims;
+    for (int s = 0; s < descents; ++s) {
         for (int k = 0; k < G; ++k) {
             hipStream_t st = e->gstream[k];
             EventPair *p = ev_begin(e, EV_SELECT, st);
@@ -262,7 +267,7 @@ static int search(azsp_engine *e, int n_act) {
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(AZSP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
     e->stats.plies++;
-    e->rounds_host += (uint64_t)e->cfg.n_sims + 1;
+    e->rounds_host += (uint64_t)descents + 1;
     e->searched = true;
     return 0;
 }
@@ -343,6 +348,22 @@ void azsp_destroy(azsp_engine *e) {
     delete e;
 }
 
+// sqrt(N), c(N) and c(N)*sqrt(N) for N = 0 .. n_sims+1, computed on the host: libm's sqrt/log are what
+// Python's math.sqrt/math.log call, so the tables are bit-identical to the reference's per-call values.
+static int upload_exploration_tables(azsp_engine *e) {
+    const int n = e->cfg.n_sims + 2;
+    std::vector<double> sq(n), ct(n), ex(n);
+    for (int i = 0; i < n; ++i) {
+        sq[i] = sqrt((double)i);
+        ct[i] = e->c_base > 0.0 ? log(((double)i + e->c_base + 1.0) / e->c_base) + e->c_init : e->c_init;
+        ex[i] = ct[i] * sq[i];                   // c == 1.0: exactly sqrt(N)
+    }
+    HIP_TRY(hipMemcpy(e->d_sqrt, sq.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_ctab, ct.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_expl, ex.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
 static int create_impl(azsp_engine *e) {
     const azsp_config &c = e->cfg;
     const GameInfo &gi = e->gi;
@@ -383,13 +404,22 @@ static int create_impl(azsp_engine *e) {
     HIP_TRY(hipMemset(v.leaf_slot, 0, (size_t)N * sizeof(int32_t)));
     HIP_TRY(hipMemset(v.n_leaf, 0, MAX_GROUPS * sizeof(int32_t)));
     DEV_ALLOC(v.eval_p, (size_t)N * AP); DEV_ALLOC(v.eval_v, N);
-    double *sq = nullptr;
-    DEV_ALLOC(sq, S + 2);
-    v.sqrt_tab = sq;
+    DEV_ALLOC(e->d_sqrt, S + 2); DEV_ALLOC(e->d_ctab, S + 2); DEV_ALLOC(e->d_expl, S + 2);
+    v.sqrt_tab = e->d_sqrt;
+    v.c_tab = e->d_ctab;
+    v.expl_tab = e->d_expl;
+    v.rules = c.search_rules;
+    v.wsum_d = nullptr;
+    if (c.search_rules == AZSP_RULES_GEN1) {
+        DEV_ALLOC(v.wsum_d, NC);
+        HIP_TRY(hipMemset(v.wsum_d, 0, NC * sizeof(double)));
+    }
+    for (int i = 0; i < 2; ++i) v.init_mine[i] = v.init_theirs[i] = 0;
     DEV_ALLOC(v.cur_mine, (size_t)N * W); DEV_ALLOC(v.cur_theirs, (size_t)N * W); DEV_ALLOC(v.cur_len, N);
     const size_t NH = (size_t)N * gi.max_plies, NA = (size_t)EPS * gi.max_plies;
     DEV_ALLOC(v.h_mine, NH * W); DEV_ALLOC(v.h_theirs, NH * W); DEV_ALLOC(v.h_counts, NH * AP);
     DEV_ALLOC(v.done, N); DEV_ALLOC(v.reward, N); DEV_ALLOC(v.chosen, N); DEV_ALLOC(v.emit_off, N);
+    DEV_ALLOC(v.h_action, NH); DEV_ALLOC(v.out_actions, NA);
     DEV_ALLOC(v.ep_offset, EPS + 1); DEV_ALLOC(v.ep_slot, EPS); DEV_ALLOC(v.ep_ply, EPS);
     DEV_ALLOC(v.out_states, NA * gi.cells); DEV_ALLOC(v.out_policies, NA * A); DEV_ALLOC(v.out_values, NA);
     DEV_ALLOC(v.totals, 4); DEV_ALLOC(v.counters, 8);
@@ -398,10 +428,9 @@ static int create_impl(azsp_engine *e) {
     DEV_ALLOC(e->d_st_counts, (size_t)N * A); DEV_ALLOC(e->d_st_w, (size_t)N * A); DEV_ALLOC(e->d_st_prior, (size_t)N * A);
     DEV_ALLOC(e->d_st_rw, N); DEV_ALLOC(e->d_st_rn, N);
     DEV_ALLOC(e->d_noise, (size_t)N * A);
+    DEV_ALLOC(e->d_st_wd, (size_t)N * A); DEV_ALLOC(e->d_st_rwd, N);
 
-    std::vector<double> tab(S + 2);
-    for (int i = 0; i < S + 2; ++i) tab[i] = sqrt((double)i);     // host libm == Python math.sqrt
-    HIP_TRY(hipMemcpy(sq, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    { int rc = upload_exploration_tables(e); if (rc) return rc; }
     HIP_TRY(hipMemset(v.counters, 0, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(v.kids, 0, NC * sizeof(int32_t)));
     HIP_TRY(hipMemset(v.prior, 0, NC * sizeof(double)));
@@ -433,6 +462,12 @@ int azsp_create(const azsp_config *cfg, azsp_engine **out) {
     if (!game_info(cfg->game, gi)) return fail(AZSP_ERR_ARG, "unknown game id %d", cfg->game);
     if (cfg->n_slots <= 0 || cfg->n_slots > (1 << 20)) return fail(AZSP_ERR_ARG, "n_slots %d out of range", cfg->n_slots);
     if (cfg->n_sims < 0 || cfg->n_sims > 65535) return fail(AZSP_ERR_ARG, "n_sims %d out of range", cfg->n_sims);
+    if (cfg->search_rules != AZSP_RULES_SIMPLE && cfg->search_rules != AZSP_RULES_GEN1)
+        return fail(AZSP_ERR_ARG, "unknown search rule set %d", cfg->search_rules);
+    if (cfg->search_rules == AZSP_RULES_GEN1 && cfg->game != AZSP_GAME_CONNECT4)
+        return fail(AZSP_ERR_ARG, "AZSP_RULES_GEN1 is defined for Connect-4 only");
+    if (cfg->search_rules == AZSP_RULES_GEN1 && cfg->n_sims < 1)
+        return fail(AZSP_ERR_ARG, "AZSP_RULES_GEN1 needs n_sims >= 1 (the root expansion is simulation 1)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(AZSP_ERR_HIP, "no HIP device available: libazsp has no CPU fallback");
@@ -529,7 +564,7 @@ int azsp_run_batch(azsp_engine *e, const int8_t *boards, int32_t n, int32_t *cou
     int32_t *d_counts = e->d_st_counts, *d_rn = e->d_st_rn;
     float *d_w = e->d_st_w, *d_rw = e->d_st_rw;
     double *d_prior = e->d_st_prior;
-    launch_root_stats(e->cfg.game, e->v, d_counts, d_w, d_prior, d_rw, d_rn, e->stream);
+    launch_root_stats(e->cfg.game, e->v, d_counts, d_w, d_prior, d_rw, d_rn, nullptr, nullptr, e->stream);
     if (counts) HIP_TRY(hipMemcpyAsync(counts, d_counts, (size_t)n * A * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     if (child_w) HIP_TRY(hipMemcpyAsync(child_w, d_w, (size_t)n * A * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     if (prior) HIP_TRY(hipMemcpyAsync(prior, d_prior, (size_t)n * A * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -560,10 +595,16 @@ int azsp_set_search_options(azsp_engine *e, const azsp_search_options *o) {
     if (!e || !o) return fail(AZSP_ERR_ARG, "null argument");
     if (o->struct_size != sizeof(azsp_search_options)) return fail(AZSP_ERR_ARG, "azsp_search_options.struct_size mismatch");
     if (o->noise_eps < 0.0 || o->noise_eps > 1.0) return fail(AZSP_ERR_ARG, "noise_eps out of [0,1]");
+    if (!(o->c_init == o->c_init) || !(o->c_base == o->c_base) || o->c_base < 0.0)
+        return fail(AZSP_ERR_ARG, "c_init / c_base must be numbers, c_base >= 0");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->stream));      // no search may be reading the tables
     e->v.sampling_plies = o->sampling_plies;
     e->v.noise_eps = o->noise_eps;
     e->v.noise_keep = 1.0 - o->noise_eps;
-    return 0;
+    e->c_init = o->c_init;
+    e->c_base = o->c_base;
+    return upload_exploration_tables(e);
 }
 
 int azsp_search_with_noise(azsp_engine *e, const double *noise) {
@@ -583,9 +624,53 @@ int azsp_root_counts(azsp_engine *e, int32_t *counts) {
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int N = e->cfg.n_slots, A = e->gi.A;
     int32_t *d_counts = e->d_st_counts;
-    launch_root_stats(e->cfg.game, e->v, d_counts, nullptr, nullptr, nullptr, nullptr, e->stream);
+    launch_root_stats(e->cfg.game, e->v, d_counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, e->stream);
     HIP_TRY(hipMemcpyAsync(counts, d_counts, (size_t)N * A * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     return sync_stream(e);
+}
+
+int azsp_root_values(azsp_engine *e, int32_t n, double *child_w, double *root_w, int32_t *root_n) {
+    if (!e || n <= 0 || n > e->cfg.n_slots) return fail(AZSP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int A = e->gi.A;
+    View v = e->v;
+    v.n_act = n;
+    v.lo = 0;
+    launch_root_stats(e->cfg.game, v, nullptr, nullptr, nullptr, nullptr, e->d_st_rn, e->d_st_wd, e->d_st_rwd, e->stream);
+    if (child_w) HIP_TRY(hipMemcpyAsync(child_w, e->d_st_wd, (size_t)n * A * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (root_w) HIP_TRY(hipMemcpyAsync(root_w, e->d_st_rwd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (root_n) HIP_TRY(hipMemcpyAsync(root_n, e->d_st_rn, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    return sync_stream(e);
+}
+
+int azsp_set_initial_board(azsp_engine *e, const int8_t *cells) {
+    if (!e) return fail(AZSP_ERR_ARG, "null engine");
+    u64 m[2] = {0, 0}, t[2] = {0, 0};
+    if (cells) {
+        int32_t term = 0;
+        int rc = azsp_game_rules(e->cfg.game, cells, -1, nullptr, nullptr, &term);
+        if (rc) return rc;
+        if (term != TERM_NONE) return fail(AZSP_ERR_ARG, "the initial position is already decided");
+        host_cells_to_bits(e->cfg.game, cells, m, t);
+    }
+    for (int i = 0; i < 2; ++i) { e->v.init_mine[i] = m[i]; e->v.init_theirs[i] = t[i]; }
+    return 0;
+}
+
+int azsp_fetch_moves(azsp_engine *e, int64_t first, int64_t n, int32_t *moves, int64_t sample_cap) {
+    if (!e || first < 0 || n < 0 || !moves) return fail(AZSP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (first + n > e->h_res->episodes_total) return fail(AZSP_ERR_ARG, "episodes not emitted yet");
+    if (n == 0) return 0;
+    int64_t off[2];
+    HIP_TRY(hipMemcpy(&off[0], e->v.ep_offset + first, sizeof(int64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&off[1], e->v.ep_offset + first + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+    const int64_t ns = off[1] - off[0];
+    if (ns > sample_cap) return fail(AZSP_ERR_ARG, "sample_cap %lld < %lld samples", (long long)sample_cap, (long long)ns);
+    std::vector<uint8_t> tmp((size_t)ns);
+    HIP_TRY(hipMemcpy(tmp.data(), e->v.out_actions + off[0], (size_t)ns, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < ns; ++i) moves[i] = tmp[(size_t)i];
+    return 0;
 }
 
 int azsp_play_begin(azsp_engine *e, const double *uniforms, int32_t *n_done) {
@@ -593,6 +678,8 @@ int azsp_play_begin(azsp_engine *e, const double *uniforms, int32_t *n_done) {
     if (!e->searched) return fail(AZSP_ERR_STATE, "azsp_play before azsp_search");
     if (e->cfg.n_sims == 0)
         return fail(AZSP_ERR_STATE, "n_sims = 0: the visit distribution is 0/0 (the reference raises in np.random.choice)");
+    if (e->cfg.search_rules == AZSP_RULES_GEN1 && e->cfg.n_sims < 2)
+        return fail(AZSP_ERR_STATE, "n_sims = 1 under AZSP_RULES_GEN1: pi = n / (N - 1) divides by zero (node.py:24-29 raises)");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int N = e->cfg.n_slots;
     HIP_TRY(hipMemcpyAsync(e->d_uniforms, uniforms, (size_t)N * sizeof(double), hipMemcpyHostToDevice, e->stream));

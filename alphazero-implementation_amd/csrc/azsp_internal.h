@@ -30,10 +30,12 @@ struct View {
     int32_t n_sims;
     int32_t max_plies; // history capacity per slot
     int32_t cells;
+    int32_t rules;     // AZSP_RULES_*: which of the reference's two search rule sets the kernels follow
 
     // search tree (SoA)
     int32_t *cnt;       // N  visit_count                       [n_slots][C]
-    float   *wsum;      // W  value_sum (float32, numpy-2 semantics)
+    float   *wsum;      // W  value_sum (float32, numpy-2 semantics)              rule set 0
+    double  *wsum_d;    // W  value_sum (Python float)                           rule set 1 (else nullptr)
     double  *prior;     // P  prior (float64; 0 = no child, monte_carlo_tree_search.py:87)
     int32_t *kids;      // first-child index
     int32_t *blk_parent;    // [n_slots][E]
@@ -49,7 +51,9 @@ struct View {
     int32_t *n_leaf;        // [MAX_GROUPS]
     float   *eval_p;        // [n_slots][AP] evaluator output (AP = A padded to 8), at offset lo, indexed by compacted leaf
     float   *eval_v;        // [n_slots]
-    const double *sqrt_tab; // [n_sims + 2] host-computed sqrt(i): bit-identical to math.sqrt
+    const double *sqrt_tab; // [n_sims + 2] host-computed sqrt(N): bit-identical to math.sqrt
+    const double *c_tab;    // [n_sims + 2] exploration factor c(N): 1.0 unless options say otherwise
+    const double *expl_tab; // [n_sims + 2] c(N) * sqrt(N)  (== sqrt_tab bit for bit while c == 1)
     // search options beyond the reference (all off by default)
     const double *root_noise;   // [n_slots][A] or nullptr
     double  noise_eps, noise_keep;   // eps and (1 - eps), both computed on the host
@@ -62,6 +66,8 @@ struct View {
     uint8_t *done;                      // [n_slots] game ended this ply
     int8_t  *reward;                    // [n_slots] reward for the side to move at the end
     int32_t *chosen;                    // [n_slots] action sampled this ply
+    uint8_t *h_action;                  // [n_slots][max_plies] history: the action taken from each root position
+    u64     init_mine[2], init_theirs[2];   // position every game starts from (canonical; all zero = empty board)
     // episode arena
     int32_t *emit_off;                  // [n_slots] sample offset of the slot's episode, -1 if none
     int64_t *ep_offset;                 // [n_slots + 1]
@@ -69,6 +75,7 @@ struct View {
     int8_t  *out_states;                // [cap][cells]
     double  *out_policies;              // [cap][A]
     int32_t *out_values;                // [cap]
+    uint8_t *out_actions;               // [cap] move played from the sample's position
     int64_t *totals;                    // [0] episodes, [1] samples, [2] ply index
     // device-side counters: [0] evals, [1] terminal leaves, [2] path nodes, [3] rounds
     unsigned long long *counters;
@@ -94,7 +101,7 @@ void launch_emit(int game, const View &v, PlyResultDev *host_result, long long c
 void launch_reset_slots(int game, const View &v, hipStream_t s);
 void launch_set_boards(int game, const View &v, const u64 *mine, const u64 *theirs, int n, hipStream_t s);
 void launch_root_stats(int game, const View &v, int32_t *counts, float *child_w, double *prior, float *root_w,
-                       int32_t *root_n, hipStream_t s);
+                       int32_t *root_n, double *child_wd, double *root_wd, hipStream_t s);
 void launch_export_records(int game, const View &v, int64_t first_sample, int64_t n_samples, void *dst,
                            hipStream_t s);
 

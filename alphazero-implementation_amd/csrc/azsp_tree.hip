@@ -16,20 +16,45 @@
 //                   Node.select_action(temperature=1) :43-61 (np.random.choice = cumsum, normalise,
 //                   searchsorted side='right' on one uniform double)
 //   k_emit_*        episode_generator.py:61-87 (z sign rule, slot restart, first-N-completions stop)
+//
+// Rule set 1 (template parameter R = 1) is the search of the reference's first-generation package,
+// src/alphazero_implementation/core/search/mcts/{search.py,node.py}: all-float64 statistics, Q used without
+// negation (search.py:33-40), the root's own expansion is the first simulation (:72-91), children exist for
+// every legal action (:87-90), no sign flip above a terminal node (:48-58).  Same kernels, compile-time branches.
+#include <type_traits>
+
 #include "azsp_internal.h"
 
 namespace azsp {
 
-#define GAME_SWITCH(game, CALL)                      \
-    switch (game) {                                  \
-        case 0: { using G = Connect4; CALL; } break; \
-        case 1: { using G = Connect2; CALL; } break; \
-        case 2: { using G = Gomoku9; CALL; } break;  \
-        default: break;                              \
+#define GAME_SWITCH(game, ...)                              \
+    switch (game) {                                         \
+        case 0: { using G = Connect4; __VA_ARGS__; } break; \
+        case 1: { using G = Connect2; __VA_ARGS__; } break; \
+        case 2: { using G = Gomoku9; __VA_ARGS__; } break;  \
+        default: break;                                     \
     }
+// the same with the rule set as a second compile-time parameter (R)
+#define RULES_SWITCH(game, rules, ...)                                            \
+    if ((rules) == 0) { constexpr int R = 0; GAME_SWITCH(game, __VA_ARGS__) }     \
+    else { constexpr int R = 1; GAME_SWITCH(game, __VA_ARGS__) }
+
+// a child exists: rule set 0 where prob != 0 (monte_carlo_tree_search.py:87); rule set 1 for every legal
+// action, marked by prior >= 0 (-1 = no child)
+template <int R>
+__device__ __forceinline__ bool child_exists(double prior) { return R == 0 ? prior != 0.0 : prior >= 0.0; }
 
 template <class G>
 static inline int games_grid(int n_games) { return (n_games * G::LPG + 63) / 64; }
+
+// the position every game starts from (all zero unless azsp_set_initial_board changed it)
+template <class G>
+__device__ __forceinline__ typename G::B initial_board(const u64 *words) {
+    typename G::B b;
+#pragma unroll
+    for (int i = 0; i < G::W; ++i) b.w[i] = words[i];
+    return b;
+}
 
 template <int LPG>
 __device__ __forceinline__ int red_add(int x) {
@@ -41,18 +66,19 @@ __device__ __forceinline__ int red_add(int x) {
 // ------------------------------------------------------------------------------------------------
 // root preparation: fresh tree per slot, root queued for evaluation (no backup: path_len = 0)
 // ------------------------------------------------------------------------------------------------
-template <class G>
+template <class G, int R>
 __global__ void k_root_prepare(View v) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= v.n_act) return;
     g += v.lo;
     size_t base = (size_t)g * v.C;
     v.cnt[base] = 0;
-    v.wsum[base] = 0.0f;
+    if constexpr (R == 0) v.wsum[base] = 0.0f; else v.wsum_d[base] = 0.0;
     v.kids[base] = 0;
     v.prior[base] = 0.0;
     v.n_blk[g] = 0;
-    v.path_len[g] = 0;
+    if constexpr (R == 0) v.path_len[g] = 0;       // run_batch :112-123: the root value is discarded
+    else { v.path_len[g] = 1; v.path[(size_t)g * v.D] = 0; }   // search.py:72-91: expanding the root IS simulation 1
     v.leaf_node[g] = 0;
     board_store<G::W>(v.leaf_mine, g, board_load<G::W>(v.cur_mine, g));
     board_store<G::W>(v.leaf_theirs, g, board_load<G::W>(v.cur_theirs, g));
@@ -62,8 +88,11 @@ __global__ void k_root_prepare(View v) {
 // ------------------------------------------------------------------------------------------------
 // selection: PUCT descent to the first unexpanded node, leaf step, terminal test
 // ------------------------------------------------------------------------------------------------
-template <class G>
+template <class G, int R>
 __global__ __launch_bounds__(64) void k_select(View v) {
+    using WT = typename std::conditional<R == 0, float, double>::type;
+    const WT *wsum_r = R == 0 ? (const WT *)v.wsum : (const WT *)v.wsum_d;
+    WT *wsum_w = R == 0 ? (WT *)v.wsum : (WT *)v.wsum_d;
     constexpr int A = G::A, LPG = G::LPG, APL = G::APL, GPW = 64 / LPG;
     static_assert(APL * LPG >= A, "every action needs a lane slot");
     extern __shared__ int s_path[];                 // [GPW games][D]
@@ -87,32 +116,39 @@ __global__ __launch_bounds__(64) void k_select(View v) {
         if (!__any(walking)) break;
         double p[APL];
         int n[APL], kc[APL];
-        float w[APL];
+        WT w[APL];
         int nsum = 0;
 #pragma unroll
         for (int k = 0; k < APL; ++k) {
             const int a = lane + k * LPG;
             const bool in = walking && a < A;
             const int child = fc + a;
-            p[k] = in ? v.prior[base + child] : 0.0;
+            p[k] = in ? v.prior[base + child] : (R == 0 ? 0.0 : -1.0);     // lanes without an action: no child
             n[k] = in ? v.cnt[base + child] : 0;
-            w[k] = in ? v.wsum[base + child] : 0.0f;
+            w[k] = in ? wsum_r[base + child] : (WT)0;
             kc[k] = in ? v.kids[base + child] : 0;
             nsum += n[k];
         }
-        const int np_ = red_add<LPG>(nsum) + (node != 0);
+        // rule set 1: the root too is counted at its expansion (search.py:72-91)
+        const int np_ = red_add<LPG>(nsum) + (R == 1 || node != 0);
         double score = -INFINITY;
         int best = lane;
 #pragma unroll
         for (int k = 0; k < APL; ++k) {
-            if (p[k] != 0.0) {                      // a child exists only where prob != 0  (:87)
-                // ucb_score :11-22.  (prior * sqrt(N_parent)) / (n + 1) in float64;
-                // -(W / n) in float32 (numpy 2.x), promoted for the sum.
-                const double u = (p[k] * v.sqrt_tab[np_]) / (double)(n[k] + 1);
-                double q = 0.0;
-                if (n[k] > 0) {
-                    const float qf = w[k] / (float)n[k];
-                    q = (double)(-qf);
+            if (child_exists<R>(p[k])) {
+                double q = 0.0, u;
+                if constexpr (R == 0) {
+                    // ucb_score :11-22.  (prior * sqrt(N_parent)) / (n + 1) in float64 [expl_tab = c * sqrt, c = 1
+                    // in the reference]; -(W / n) in float32 (numpy 2.x), promoted for the sum.
+                    u = (p[k] * v.expl_tab[np_]) / (double)(n[k] + 1);
+                    if (n[k] > 0) {
+                        const float qf = w[k] / (float)n[k];
+                        q = (double)(-qf);
+                    }
+                } else {
+                    // search.py:33-40: child.value + c * prior * sqrt(N) / (1 + n), left to right, all float64
+                    u = ((v.c_tab[np_] * p[k]) * v.sqrt_tab[np_]) / (double)(1 + n[k]);
+                    if (n[k] > 0) q = w[k] / (double)n[k];
                 }
                 double sc = q + u;
                 if (!(sc == sc)) sc = -INFINITY;    // NaN is never '>' the running best
@@ -154,13 +190,16 @@ __global__ __launch_bounds__(64) void k_select(View v) {
         term = G::terminal(nm, nt);
     }
     if (live && term != TERM_NONE) {
-        // terminal leaf: never expanded, value in {+1,-1,0}; backpropagate :214-223.  The sign
-        // alternates with distance from the leaf (to_play alternates level by level).
-        const float val = (float)term;
+        // terminal leaf: never expanded.  Rule set 0: value in {+1,-1,0} for the side to move at the leaf,
+        // backpropagate :214-223 -- the sign alternates with distance from the leaf (to_play alternates level by
+        // level).  Rule set 1 (search.py:78-80,:48-58): the utility of the player who MOVED into the leaf, added
+        // unchanged to the leaf and to its parent (no flip above a terminal node), alternating from there on.
+        const WT val = R == 0 ? (WT)term : (term == 0 ? (WT)0 : (WT)(-term));
         for (int k = lane; k < L; k += LPG) {
             const int nd = my_path[L - 1 - k];
-            const float dv = (k & 1) ? -val : val;
-            v.wsum[base + nd] = v.wsum[base + nd] + dv;
+            const bool neg = R == 0 ? (k & 1) : (k > 0 && ((k - 1) & 1));
+            const WT dv = neg ? -val : val;
+            wsum_w[base + nd] = wsum_r[base + nd] + dv;
             v.cnt[base + nd] = v.cnt[base + nd] + 1;
         }
         if (lane == 0) {
@@ -226,9 +265,11 @@ __global__ void k_eval_hash(View v, uint64_t salt) {
 // ------------------------------------------------------------------------------------------------
 // expansion + backup of the evaluated leaves
 // ------------------------------------------------------------------------------------------------
-template <class G>
+template <class G, int R>
 __global__ __launch_bounds__(64) void k_expand(View v) {
     constexpr int A = G::A, LPG = G::LPG, APL = G::APL, GPW = 64 / LPG;
+    using WT = typename std::conditional<R == 0, float, double>::type;
+    WT *wsum = R == 0 ? (WT *)v.wsum : (WT *)v.wsum_d;
     __shared__ double s_pa[GPW][G::AP];             // staged priors for numpy's pairwise summation
     const int lane = threadIdx.x & (LPG - 1);
     const int grp = threadIdx.x / LPG;
@@ -241,16 +282,22 @@ __global__ __launch_bounds__(64) void k_expand(View v) {
 
     // action_probs * valid_moves -> float64 ; /= np.sum(action_probs)
     double pa[APL];
+    bool ok[APL];
 #pragma unroll
     for (int k = 0; k < APL; ++k) {
         const int a = lane + k * LPG;
         pa[k] = 0.0;
-        if (live && a < A) pa[k] = (double)v.eval_p[(size_t)j * G::AP + a] * (double)(G::legal(mine, theirs, a) ? 1 : 0);
+        ok[k] = live && a < A && G::legal(mine, theirs, a);
+        if (live && a < A) pa[k] = (double)v.eval_p[(size_t)j * G::AP + a] * (double)(ok[k] ? 1 : 0);
         if (a < G::AP) s_pa[grp][a] = pa[k];
     }
     __syncthreads();
     double s = 0.0;
-    if constexpr (A < 8) {                          // numpy: plain left-to-right loop for fewer than 8 elements
+    if constexpr (R == 1) {
+        // search.py:85-90: the model's probabilities are used as they come (models/games/connect4/model.py:33-40
+        // already took the softmax over the legal moves); no renormalisation
+        s = 1.0;
+    } else if constexpr (A < 8) {                          // numpy: plain left-to-right loop for fewer than 8 elements
 #pragma unroll
         for (int a = 0; a < A; ++a) s = s + s_pa[grp][a];
     } else {
@@ -277,22 +324,24 @@ __global__ __launch_bounds__(64) void k_expand(View v) {
     for (int k = 0; k < APL; ++k) {
         const int a = lane + k * LPG;
         if (a >= A) continue;
-        const double pr = pa[k] / s;
+        const double pr = R == 0 ? pa[k] / s : (ok[k] ? pa[k] : -1.0);
         double prior = pr;
         // optional root exploration noise (off by default; not in the reference's search, listed in its
         // src/deepmind_alphazero_pseudocode.py:285-290): prior*(1-eps) + noise*eps on the existing root children
-        if (L == 0 && v.root_noise != nullptr && pr != 0.0)
+        if (node == 0 && v.root_noise != nullptr && child_exists<R>(pr))
             prior = pr * v.noise_keep + v.root_noise[(size_t)g * A + a] * v.noise_eps;
         v.cnt[base + fc + a] = 0;                   // Node.expand :80-90
-        v.wsum[base + fc + a] = 0.0f;
+        wsum[base + fc + a] = (WT)0;
         v.prior[base + fc + a] = prior;
         v.kids[base + fc + a] = 0;
     }
-    const float val = v.eval_v[j];
-    for (int k = lane; k < L; k += LPG) {           // backpropagate :214-223
+    // the value is the evaluator's float32 for the side to move at the leaf (rule set 1: value[state.player],
+    // a float32 widened by .tolist(), search.py:91); signs alternate upwards in both rule sets
+    const WT val = (WT)v.eval_v[j];
+    for (int k = lane; k < L; k += LPG) {           // backpropagate :214-223 / search.py:48-58
         const int nd = v.path[(size_t)g * v.D + (L - 1 - k)];
-        const float dv = (k & 1) ? -val : val;
-        v.wsum[base + nd] = v.wsum[base + nd] + dv;
+        const WT dv = (k & 1) ? -val : val;
+        wsum[base + nd] = wsum[base + nd] + dv;
         v.cnt[base + nd] = v.cnt[base + nd] + 1;
     }
     __syncthreads();                                // all lanes have read n_blk
@@ -318,7 +367,7 @@ __global__ void k_leaf_cells(View v, int8_t *dst) {
 // ------------------------------------------------------------------------------------------------
 // end of ply: pi, sample, apply, terminal test
 // ------------------------------------------------------------------------------------------------
-template <class G>
+template <class G, int R>
 __global__ __launch_bounds__(64) void k_finish(View v, const double *uniforms) {
     constexpr int A = G::A, LPG = G::LPG, APL = G::APL, GPW = 64 / LPG;
     __shared__ int s_cnt[GPW][G::AP];
@@ -337,7 +386,7 @@ __global__ __launch_bounds__(64) void k_finish(View v, const double *uniforms) {
         if (a >= G::AP) continue;
         int c = 0, ex = 0;
         if (live && a < A) {
-            ex = v.prior[base + 1 + a] != 0.0;      // root.children keys
+            ex = child_exists<R>(v.prior[base + 1 + a]);      // root.children keys
             c = ex ? v.cnt[base + 1 + a] : 0;
         }
         s_cnt[grp][a] = c;
@@ -382,6 +431,7 @@ __global__ __launch_bounds__(64) void k_finish(View v, const double *uniforms) {
     board_store<G::W>(v.cur_theirs, g, nt);
     v.cur_len[g] = len + 1;
     v.chosen[g] = act;
+    v.h_action[h] = (uint8_t)act;
     v.done[g] = term != TERM_NONE;
     v.reward[g] = (int8_t)(term == TERM_NONE ? 0 : term);
 }
@@ -506,12 +556,15 @@ __global__ __launch_bounds__(64) void k_emit_copy(View v) {
                 v.out_states[(size_t)(off + q) * G::CELLS + cell] = (int8_t)(board_bit(m, b) ? 1 : (board_bit(t, b) ? -1 : 0));
             }
             // value = reward * (-1)**(hist_player != final_player)  (:73-74); players alternate
-            if (lane == 0) v.out_values[off + q] = ((len - q) & 1) ? -rew : rew;
+            if (lane == 0) {
+                v.out_values[off + q] = ((len - q) & 1) ? -rew : rew;
+                v.out_actions[off + q] = v.h_action[h];
+            }
         }
     }
     if (lane == 0) {                                // :80-82 fresh game in this slot
-        board_store<G::W>(v.cur_mine, g, board_zero<G::W>());
-        board_store<G::W>(v.cur_theirs, g, board_zero<G::W>());
+        board_store<G::W>(v.cur_mine, g, initial_board<G>(v.init_mine));
+        board_store<G::W>(v.cur_theirs, g, initial_board<G>(v.init_theirs));
         v.cur_len[g] = 0;
     }
 }
@@ -521,8 +574,8 @@ __global__ void k_reset_slots(View v) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g == 0) { v.totals[0] = 0; v.totals[1] = 0; v.totals[2] = 0; v.ep_offset[0] = 0; }
     if (g >= v.n_slots) return;
-    board_store<G::W>(v.cur_mine, g, board_zero<G::W>());
-    board_store<G::W>(v.cur_theirs, g, board_zero<G::W>());
+    board_store<G::W>(v.cur_mine, g, initial_board<G>(v.init_mine));
+    board_store<G::W>(v.cur_theirs, g, initial_board<G>(v.init_theirs));
     v.cur_len[g] = 0;
     v.done[g] = 0;
     v.pending[g] = 0;
@@ -537,19 +590,24 @@ __global__ void k_set_boards(View v, const u64 *mine, const u64 *theirs, int n) 
     v.cur_len[g] = 0;
 }
 
-template <class G>
-__global__ void k_root_stats(View v, int32_t *counts, float *child_w, double *prior, float *root_w, int32_t *root_n) {
+template <class G, int R>
+__global__ void k_root_stats(View v, int32_t *counts, float *child_w, double *prior, float *root_w, int32_t *root_n,
+                             double *child_wd, double *root_wd) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.n_act * G::A) return;
     const int g = i / G::A, a = i % G::A;
     const size_t base = (size_t)g * v.C;
     const double p = v.prior[base + 1 + a];
-    const bool ex = p != 0.0;
+    const bool ex = child_exists<R>(p);
+    const double w = ex ? (R == 0 ? (double)v.wsum[base + 1 + a] : v.wsum_d[base + 1 + a]) : 0.0;
     if (counts) counts[i] = ex ? v.cnt[base + 1 + a] : 0;
-    if (child_w) child_w[i] = ex ? v.wsum[base + 1 + a] : 0.0f;
+    if (child_w) child_w[i] = (float)w;
+    if (child_wd) child_wd[i] = w;
     if (prior) prior[i] = ex ? p : 0.0;
     if (a == 0) {
-        if (root_w) root_w[g] = v.wsum[base];
+        const double rw = R == 0 ? (double)v.wsum[base] : v.wsum_d[base];
+        if (root_w) root_w[g] = (float)rw;
+        if (root_wd) root_wd[g] = rw;
         if (root_n) root_n[g] = v.cnt[base];
     }
 }
@@ -596,24 +654,24 @@ __global__ void k_export_dataset(View v, long long first, long long n, float *pl
 // launchers
 // ------------------------------------------------------------------------------------------------
 void launch_root_prepare(int game, const View &v, hipStream_t s) {
-    GAME_SWITCH(game, hipLaunchKernelGGL(k_root_prepare<G>, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v));
+    RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_root_prepare<G, R>), dim3((v.n_act + 255) / 256), dim3(256), 0, s, v));
 }
 void launch_select(int game, const View &v, hipStream_t s) {
-    GAME_SWITCH(game, hipLaunchKernelGGL(k_select<G>, dim3(games_grid<G>(v.n_act)), dim3(64),
-                                         (size_t)(64 / G::LPG) * v.D * sizeof(int), s, v));
+    RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select<G, R>), dim3(games_grid<G>(v.n_act)), dim3(64),
+                                                    (size_t)(64 / G::LPG) * v.D * sizeof(int), s, v));
 }
 void launch_compact(const View &v, hipStream_t s) { hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, v); }
 void launch_eval_hash(int game, const View &v, uint64_t salt, hipStream_t s) {
     GAME_SWITCH(game, hipLaunchKernelGGL(k_eval_hash<G>, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v, salt));
 }
 void launch_expand(int game, const View &v, hipStream_t s) {
-    GAME_SWITCH(game, hipLaunchKernelGGL(k_expand<G>, dim3(games_grid<G>(v.n_act)), dim3(64), 0, s, v));
+    RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expand<G, R>), dim3(games_grid<G>(v.n_act)), dim3(64), 0, s, v));
 }
 void launch_leaf_cells(int game, const View &v, int8_t *dst, hipStream_t s) {
     GAME_SWITCH(game, hipLaunchKernelGGL(k_leaf_cells<G>, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v, dst));
 }
 void launch_finish(int game, const View &v, const double *uniforms, hipStream_t s) {
-    GAME_SWITCH(game, hipLaunchKernelGGL(k_finish<G>, dim3(games_grid<G>(v.n_act)), dim3(64), 0, s, v, uniforms));
+    RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_finish<G, R>), dim3(games_grid<G>(v.n_act)), dim3(64), 0, s, v, uniforms));
 }
 void launch_count_done(const View &v, int32_t *out, hipStream_t s) {
     hipLaunchKernelGGL(k_count_done, dim3(1), dim3(1024), 0, s, v, out);
@@ -629,9 +687,9 @@ void launch_set_boards(int game, const View &v, const u64 *mine, const u64 *thei
     GAME_SWITCH(game, hipLaunchKernelGGL(k_set_boards<G>, dim3((n + 255) / 256), dim3(256), 0, s, v, mine, theirs, n));
 }
 void launch_root_stats(int game, const View &v, int32_t *counts, float *child_w, double *prior, float *root_w,
-                       int32_t *root_n, hipStream_t s) {
-    GAME_SWITCH(game, hipLaunchKernelGGL(k_root_stats<G>, dim3((v.n_act * G::A + 255) / 256), dim3(256), 0, s, v,
-                                         counts, child_w, prior, root_w, root_n));
+                       int32_t *root_n, double *child_wd, double *root_wd, hipStream_t s) {
+    RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_root_stats<G, R>), dim3((v.n_act * G::A + 255) / 256), dim3(256), 0, s, v,
+                                                    counts, child_w, prior, root_w, root_n, child_wd, root_wd));
 }
 void launch_export_records(int game, const View &v, int64_t first, int64_t n, void *dst, hipStream_t s) {
     if (n <= 0) return;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AZSP_ABI_VERSION 1
+#define AZSP_ABI_VERSION 2
 
 typedef struct azsp_engine azsp_engine;
 
@@ -36,8 +36,17 @@ typedef struct azsp_engine azsp_engine;
 enum { AZSP_GAME_CONNECT4 = 0,   /* src/alphazero_simple/connect4_game.py:6-101 */
        AZSP_GAME_CONNECT2 = 1,   /* src/alphazero_simple/connect2_game.py:6-80  */
        AZSP_GAME_GOMOKU9  = 2 }; /* 9x9, five in a row: NOT in the reference -- device side of the new BaseGame plugin
-                                    alphazero-implementation_amd/azsp/games.py GomokuGame (BASELINE.json configs[4]);
-                                    hash / host evaluators only (no device network yet)                          */
+                                    alphazero-implementation_amd/azsp/games.py GomokuGame (BASELINE.json configs[4]) */
+
+/* Search rule sets: the reference holds two generations of the same batched search; the arithmetic differs.
+ *   AZSP_RULES_SIMPLE  src/alphazero_simple/monte_carlo_tree_search.py:11-223 (what alphazero_less_simple's
+ *                      EpisodeGenerator calls): W float32, score = -(W/n) + P*sqrt(N)/(n+1), priors masked and
+ *                      renormalised, children where prob != 0, root value discarded, n_sims descents per ply.
+ *   AZSP_RULES_GEN1    src/alphazero_implementation/core/search/mcts/search.py:10-91 + node.py:7-73: W float64,
+ *                      score = W/n + c*P*sqrt(N)/(1+n) (no negation), priors taken as the model gives them, a child
+ *                      for every legal action, the root's expansion is simulation 1 (so pi = n/(N-1)), no sign
+ *                      flip above a terminal node.  Connect-4 only (the package hard-codes simulator.game.connect). */
+enum { AZSP_RULES_SIMPLE = 0, AZSP_RULES_GEN1 = 1 };
 
 /* Evaluator kinds: what stands behind BaseModel.predict (src/alphazero_simple/base_model.py:52-58). */
 enum { AZSP_EVAL_RESNET = 0,  /* on-device fp32 MFMA forward of ResNet (src/alphazero_simple/resnet.py:30-157) */
@@ -67,6 +76,8 @@ typedef struct azsp_config {
                                 0 = automatic.  Results do not depend on it.                          */
     int32_t  arena_episodes; /* episode capacity of the output arena; 0 = n_slots.  The sharded exact mode
                                 (azsp_play_begin/commit) lets one shard emit more than its own n_slots.    */
+    int32_t  search_rules;   /* AZSP_RULES_*                                                           */
+    int32_t  reserved;       /* 0                                                                      */
 } azsp_config;
 
 /* Host evaluator: boards int8[n][cells] (canonical) -> p float32[n][n_actions], v float32[n].
@@ -143,10 +154,18 @@ int  azsp_predict(azsp_engine *e, const int8_t *boards, int32_t n, float *p_out,
  *   root_w  float [n]     root.value_sum          root_n int32[n]  root.visit_count */
 int  azsp_run_batch(azsp_engine *e, const int8_t *boards, int32_t n, int32_t *counts, float *child_w,
                     double *prior, float *root_w, int32_t *root_n);
+/* value_sum of the first n trees of the search just run, as float64 (exact in both rule sets; with
+ * AZSP_RULES_GEN1 azsp_run_batch's float outputs are rounded): child_w double[n][A], root_w double[n],
+ * root_n int32[n] -- Node.value = value_sum / visit_count (node.py:50-55, AlphaZeroSearch.run search.py:60-64) */
+int  azsp_root_values(azsp_engine *e, int32_t n, double *child_w, double *root_w, int32_t *root_n);
 
 /* ---- episode generation: EpisodeGenerator.generate_episodes
  *      (src/alphazero_less_simple/core/training/episode_generator.py:23-87) --------------------- */
 int  azsp_reset(azsp_engine *e);                       /* :25-29  fresh games in every slot          */
+/* The position every game starts from (canonical cells; NULL = empty board, the default).  Stands behind
+ * generate_episodes(initial_state) of src/alphazero_implementation/core/training/episode_generator.py:35-45.
+ * Takes effect at the next azsp_reset and at every slot restart. */
+int  azsp_set_initial_board(azsp_engine *e, const int8_t *cells);
 int  azsp_search(azsp_engine *e);                      /* :31-36  run_batch on the slots' boards     */
 int  azsp_root_counts(azsp_engine *e, int32_t *counts);/* int32[n_slots][A] of the search just run   */
 /* Search options the reference does NOT have (its generator fixes temperature = 1 and uses no noise,
@@ -155,8 +174,13 @@ int  azsp_root_counts(azsp_engine *e, int32_t *counts);/* int32[n_slots][A] of t
  *   sampling_plies >= 0: after that many plies of a game the move is arg-max of the visit counts
  *                        (Node.select_action(temperature=0), monte_carlo_tree_search.py:49-50); < 0 = always sample
  *   noise_eps > 0      : azsp_search_with_noise mixes caller-drawn noise into the root priors,
- *                        prior*(1-eps) + noise*eps on existing children (noise double[n_slots][A]) */
-typedef struct azsp_search_options { uint32_t struct_size; int32_t sampling_plies; double noise_eps; } azsp_search_options;
+ *                        prior*(1-eps) + noise*eps on existing children (noise double[n_slots][A])
+ *   c_init, c_base     : exploration factor c(N) multiplying P*sqrt(N)/(n+1): c_base <= 0 -> the constant c_init
+ *                        (1.0 = the reference's implicit c_puct, monte_carlo_tree_search.py:14-17; the
+ *                        `exploration_weight` of search.py:16,35 under AZSP_RULES_GEN1); c_base > 0 ->
+ *                        log((N + c_base + 1) / c_base) + c_init, the pb_c of deepmind_alphazero_pseudocode.py:252-255 */
+typedef struct azsp_search_options { uint32_t struct_size; int32_t sampling_plies; double noise_eps;
+                                     double c_init, c_base; } azsp_search_options;
 int  azsp_set_search_options(azsp_engine *e, const azsp_search_options *opts);
 int  azsp_search_with_noise(azsp_engine *e, const double *noise);
 /* :38-87  pi, sample (one uniform per slot, slot order), apply, terminal test, emit, restart.      */
@@ -181,6 +205,9 @@ int  azsp_fetch_episodes(azsp_engine *e, int64_t first, int64_t n, int64_t *ep_o
 /* Device-side export for the multi-GPU all-gather: packs the samples of episodes [first, first+n)
  * into caller-owned DEVICE memory as records of azsp_record_bytes() bytes:
  *   int8 state[cells] | int8 value | pad to 8 | double policy[A].  Returns the number of records. */
+/* The move played from each sample position of episodes [first, first+n): int32[S].  (The gen-1 samples hold
+ * simulator State objects, episode.py:12-19: the adapter rebuilds them by replaying these moves.) */
+int  azsp_fetch_moves(azsp_engine *e, int64_t first, int64_t n, int32_t *moves, int64_t sample_cap);
 int64_t azsp_export_records_device(azsp_engine *e, int64_t first, int64_t n, void *dev_dst, int64_t cap_records);
 int32_t azsp_record_bytes(int32_t game);
 /* Training tensors of episodes [first, first+n) written into caller-owned DEVICE memory, in the layout

@@ -330,10 +330,10 @@ class ONode:
             if pr != 0:
                 self.kids[a] = ONode(pr, -self.to_play, self)
 
-    def best_child(self):                          # :63-78  strict '>' from -inf: first maximum wins
+    def best_child(self, c_of=None):               # :63-78  strict '>' from -inf: first maximum wins
         top, top_a, top_c = -np.inf, -1, None
         for a, c in self.kids.items():
-            s = puct(self, c)
+            s = puct(self, c, c_of)
             if s > top:
                 top, top_a, top_c = s, a, c
         return top_a, top_c
@@ -350,9 +350,20 @@ class ONode:
         return sample_from(acts, d, rng)
 
 
-def puct(parent: ONode, child: ONode):             # :11-22
-    u = child.prior * math.sqrt(parent.n) / (child.n + 1)
+def puct(parent: ONode, child: ONode, c_of=None):  # :11-22
+    """`c_of` (EXTENSION, None = the reference): exploration factor c(N); the bonus becomes
+    prior * (c(N) * sqrt(N)) / (n + 1) -- with c == 1.0 bit-identical to the reference's expression."""
+    root_n = math.sqrt(parent.n) if c_of is None else c_of(parent.n) * math.sqrt(parent.n)
+    u = child.prior * root_n / (child.n + 1)
     return (-child.q() if child.n > 0 else 0) + u
+
+
+def exploration_factor(c_init: float = 1.0, c_base: float = 0.0):
+    """c(N) of the engine's search options: the constant c_init, or with c_base > 0 the
+    log((N + c_base + 1) / c_base) + c_init of src/deepmind_alphazero_pseudocode.py:252-255."""
+    if c_base > 0:
+        return lambda n: math.log((n + c_base + 1) / c_base) + c_init
+    return lambda n: c_init
 
 
 def sample_from(acts, p, rng=np.random):
@@ -379,7 +390,8 @@ def masked_priors(p32, valid):                     # :119-121 and :165-167
     return pr
 
 
-def run_batch(rules, predict: Callable, sims: int, states, to_plays, root_noise=None, noise_eps: float = 0.0) -> list[ONode]:
+def run_batch(rules, predict: Callable, sims: int, states, to_plays, root_noise=None, noise_eps: float = 0.0,
+              c_of=None) -> list[ONode]:
     """monte_carlo_tree_search.py:111-171.  `root_noise` (array [n][A]) / `noise_eps` are an EXTENSION beyond the
     reference (off by default): root priors become prior*(1-eps) + noise*eps on existing children, the scheme of
     the reference's src/deepmind_alphazero_pseudocode.py:285-290."""
@@ -399,7 +411,7 @@ def run_batch(rules, predict: Callable, sims: int, states, to_plays, root_noise=
         for root in roots:                                          # :129
             node, act = root, -1
             while node.is_expanded():                               # :130-133
-                act, node = node.best_child()
+                act, node = node.best_child(c_of)
             par = node.up
             nxt, _ = rules.next_state(par.state, 1, act)            # :140 mover is always +1
             nxt = rules.canonical(nxt, -1)                          # :142
@@ -429,7 +441,7 @@ def root_counts(root: ONode, n_actions: int) -> list[int]:
 # --------------------------------------------------------------------------------------------
 def generate_episodes(rules, predict: Callable, sims: int, n_slots: int, rng=np.random,
                       trace: list | None = None, sampling_plies: int | None = None,
-                      dirichlet_alpha: float | None = None, dirichlet_eps: float = 0.25):
+                      dirichlet_alpha: float | None = None, dirichlet_eps: float = 0.25, c_of=None):
     """Yields episodes in the reference's (ply, slot) order; each episode is a list of
     (canonical_state int64, policy float64[A], value int).  ``trace`` (optional) receives one
     dict per (ply, slot) with the root visit counts and the chosen action.
@@ -447,7 +459,7 @@ def generate_episodes(rules, predict: Callable, sims: int, n_slots: int, rng=np.
     while True:                                                      # :30
         canon = [rules.canonical(s, p) for s, p in zip(states, players)]   # :31-34
         noise = rng.gamma(dirichlet_alpha, 1.0, (n_slots, A)) if dirichlet_alpha else None
-        roots = run_batch(rules, predict, sims, canon, players, noise, dirichlet_eps if dirichlet_alpha else 0.0)   # :36
+        roots = run_batch(rules, predict, sims, canon, players, noise, dirichlet_eps if dirichlet_alpha else 0.0, c_of)   # :36
         for i in range(n_slots):                                     # :38-44 slot order = RNG order
             root = roots[i]
             counts = root_counts(root, A)

@@ -38,7 +38,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.azsp_abi_version() == 1
+    assert lib.azsp_abi_version() == _lib.ABI_VERSION == 2
     import ctypes as C
     r, c, a, mp = (C.c_int32() for _ in range(4))
     assert lib.azsp_game_info(0, C.byref(r), C.byref(c), C.byref(a), C.byref(mp)) == 0
@@ -210,3 +210,59 @@ def test_gomoku_device_trait_matches_oracle_rules_on_host():
     for i in range(5):
         lines[4 + i, 8 - i] = -1                        # anti-diagonal reaching the last row
     check(lines, 0)
+
+
+# ------------------------------------------------------------------------------------ gen-1 surface (host side)
+def test_connect_state_agrees_with_the_gen1_oracle_rules():
+    """azsp.connect_state (the stand-in for `simulator.game.connect`) against the oracle's independent rules, and
+    against the engine's canonical encoding through the reference-pinned Connect-4 rules: random playouts."""
+    from azsp import connect_state as cs
+    from azsp.gen1 import canonical_cells, grid_from_cells
+    from oracle import gen1_oracle as g1
+    from oracle import az_oracle as oz
+    rng = np.random.RandomState(0)
+    rules = oz.C4Rules()
+    ended = 0
+    for _ in range(300):
+        s, o = cs.Config(6, 7, 4).sample_initial_state(), g1.GConfig().sample_initial_state()
+        board, player = rules.init_board(), 1
+        while True:
+            assert np.array_equal(s.grid, o.grid) and s.player == o.player and s.has_ended == o.has_ended
+            assert s.reward.tolist() == o.reward.tolist()
+            assert [a.column for a in s.actions] == [a.column for a in o.actions]
+            cells = canonical_cells(s)
+            assert np.array_equal(cells, rules.canonical(board, player))        # same position, engine encoding
+            assert np.array_equal(grid_from_cells(cells, s.player), s.grid)
+            if s.has_ended:
+                # reference rules: reward for the player to move (-1 lost / 0 draw) <-> +1 for the previous mover
+                rew = rules.reward(board, player)
+                assert rew is not None and s.reward[1 - s.player] == -rew
+                ended += 1
+                break
+            assert rules.reward(board, player) is None
+            assert [a.column for a in s.actions] == [c for c, v in enumerate(rules.valid_moves(board)) if v]
+            k = int(rng.randint(len(s.actions)))
+            col = s.actions[k].column
+            s, o = s.actions[k].sample_next_state(), o.actions[k].sample_next_state()
+            board, player = rules.next_state(board, player, col)
+    assert ended == 300
+
+
+def test_gen1_records_json_and_model_surface():
+    from azsp import connect_state as cs
+    from azsp import gen1
+    s = cs.Config().sample_initial_state()
+    s = s.actions[3].sample_next_state()
+    assert cs.State.from_json(s.to_json()) == s
+    a = s.actions[2]
+    assert cs.Action.from_json(a.to_json()) == a and hash(cs.Action.from_json(a.to_json())) == hash(a)
+    ep = gen1.Episode()
+    ep.add_sample(gen1.Sample(state=s, policy={x: 1 / 7 for x in s.actions}, value=[0.0, 0.0]))
+    ep.backpropagate_outcome([1.0, -1.0])
+    d = ep.to_dict()
+    assert d["samples"][0]["value"] == [1.0, -1.0] and len(d["samples"][0]["policy"]) == 7
+    assert d["samples"][0]["state"] == s.to_json() and ep.current_state is s
+    with pytest.raises(TypeError):
+        gen1.Model()                       # abstract: predict must be provided  (models/base/model.py:54)
+    with pytest.raises(NotImplementedError):
+        gen1._check_connect4(cs.Config(5, 5, 3).sample_initial_state())
