@@ -410,7 +410,7 @@ static int create_impl(azsp_engine *e) {
     v.expl_tab = e->d_expl;
     v.rules = c.search_rules;
     v.wsum_d = nullptr;
-    if (c.search_rules == AZSP_RULES_GEN1) {
+    if (c.search_rules != AZSP_RULES_SIMPLE) {
         DEV_ALLOC(v.wsum_d, NC);
         HIP_TRY(hipMemset(v.wsum_d, 0, NC * sizeof(double)));
     }
@@ -462,7 +462,7 @@ int azsp_create(const azsp_config *cfg, azsp_engine **out) {
     if (!game_info(cfg->game, gi)) return fail(AZSP_ERR_ARG, "unknown game id %d", cfg->game);
     if (cfg->n_slots <= 0 || cfg->n_slots > (1 << 20)) return fail(AZSP_ERR_ARG, "n_slots %d out of range", cfg->n_slots);
     if (cfg->n_sims < 0 || cfg->n_sims > 65535) return fail(AZSP_ERR_ARG, "n_sims %d out of range", cfg->n_sims);
-    if (cfg->search_rules != AZSP_RULES_SIMPLE && cfg->search_rules != AZSP_RULES_GEN1)
+    if (cfg->search_rules < AZSP_RULES_SIMPLE || cfg->search_rules > AZSP_RULES_SIMPLE_NUMPY1)
         return fail(AZSP_ERR_ARG, "unknown search rule set %d", cfg->search_rules);
     if (cfg->search_rules == AZSP_RULES_GEN1 && cfg->game != AZSP_GAME_CONNECT4)
         return fail(AZSP_ERR_ARG, "AZSP_RULES_GEN1 is defined for Connect-4 only");

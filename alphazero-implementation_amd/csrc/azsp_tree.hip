@@ -21,6 +21,7 @@
 // src/alphazero_implementation/core/search/mcts/{search.py,node.py}: all-float64 statistics, Q used without
 // negation (search.py:33-40), the root's own expansion is the first simulation (:72-91), children exist for
 // every legal action (:87-90), no sign flip above a terminal node (:48-58).  Same kernels, compile-time branches.
+// R = 2 is rule set 0 with the float64 value sums numpy 1.x would produce (see include/azsp.h).
 #include <type_traits>
 
 #include "azsp_internal.h"
@@ -35,14 +36,15 @@ namespace azsp {
         default: break;                                     \
     }
 // the same with the rule set as a second compile-time parameter (R)
-#define RULES_SWITCH(game, rules, ...)                                            \
-    if ((rules) == 0) { constexpr int R = 0; GAME_SWITCH(game, __VA_ARGS__) }     \
-    else { constexpr int R = 1; GAME_SWITCH(game, __VA_ARGS__) }
+#define RULES_SWITCH(game, rules, ...)                                                 \
+    if ((rules) == 0) { constexpr int R = 0; GAME_SWITCH(game, __VA_ARGS__) }          \
+    else if ((rules) == 1) { constexpr int R = 1; GAME_SWITCH(game, __VA_ARGS__) }     \
+    else { constexpr int R = 2; GAME_SWITCH(game, __VA_ARGS__) }
 
 // a child exists: rule set 0 where prob != 0 (monte_carlo_tree_search.py:87); rule set 1 for every legal
 // action, marked by prior >= 0 (-1 = no child)
 template <int R>
-__device__ __forceinline__ bool child_exists(double prior) { return R == 0 ? prior != 0.0 : prior >= 0.0; }
+__device__ __forceinline__ bool child_exists(double prior) { return R != 1 ? prior != 0.0 : prior >= 0.0; }
 
 template <class G>
 static inline int games_grid(int n_games) { return (n_games * G::LPG + 63) / 64; }
@@ -77,7 +79,7 @@ __global__ void k_root_prepare(View v) {
     v.kids[base] = 0;
     v.prior[base] = 0.0;
     v.n_blk[g] = 0;
-    if constexpr (R == 0) v.path_len[g] = 0;       // run_batch :112-123: the root value is discarded
+    if constexpr (R != 1) v.path_len[g] = 0;       // run_batch :112-123: the root value is discarded
     else { v.path_len[g] = 1; v.path[(size_t)g * v.D] = 0; }   // search.py:72-91: expanding the root IS simulation 1
     v.leaf_node[g] = 0;
     board_store<G::W>(v.leaf_mine, g, board_load<G::W>(v.cur_mine, g));
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64) void k_select(View v) {
             const int a = lane + k * LPG;
             const bool in = walking && a < A;
             const int child = fc + a;
-            p[k] = in ? v.prior[base + child] : (R == 0 ? 0.0 : -1.0);     // lanes without an action: no child
+            p[k] = in ? v.prior[base + child] : (R != 1 ? 0.0 : -1.0);     // lanes without an action: no child
             n[k] = in ? v.cnt[base + child] : 0;
             w[k] = in ? wsum_r[base + child] : (WT)0;
             kc[k] = in ? v.kids[base + child] : 0;
@@ -145,6 +147,11 @@ __global__ __launch_bounds__(64) void k_select(View v) {
                         const float qf = w[k] / (float)n[k];
                         q = (double)(-qf);
                     }
+                } else if constexpr (R == 2) {
+                    // the same expression as numpy 1.x evaluates it: W is float64 there (legacy scalar promotion
+                    // of `0.0 + np.float32`), so -(W / n) is a float64 division
+                    u = (p[k] * v.expl_tab[np_]) / (double)(n[k] + 1);
+                    if (n[k] > 0) q = -(w[k] / (double)n[k]);
                 } else {
                     // search.py:33-40: child.value + c * prior * sqrt(N) / (1 + n), left to right, all float64
                     u = ((v.c_tab[np_] * p[k]) * v.sqrt_tab[np_]) / (double)(1 + n[k]);
@@ -194,10 +201,10 @@ __global__ __launch_bounds__(64) void k_select(View v) {
         // backpropagate :214-223 -- the sign alternates with distance from the leaf (to_play alternates level by
         // level).  Rule set 1 (search.py:78-80,:48-58): the utility of the player who MOVED into the leaf, added
         // unchanged to the leaf and to its parent (no flip above a terminal node), alternating from there on.
-        const WT val = R == 0 ? (WT)term : (term == 0 ? (WT)0 : (WT)(-term));
+        const WT val = R != 1 ? (WT)term : (term == 0 ? (WT)0 : (WT)(-term));
         for (int k = lane; k < L; k += LPG) {
             const int nd = my_path[L - 1 - k];
-            const bool neg = R == 0 ? (k & 1) : (k > 0 && ((k - 1) & 1));
+            const bool neg = R != 1 ? (k & 1) : (k > 0 && ((k - 1) & 1));
             const WT dv = neg ? -val : val;
             wsum_w[base + nd] = wsum_r[base + nd] + dv;
             v.cnt[base + nd] = v.cnt[base + nd] + 1;
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(64) void k_expand(View v) {
     for (int k = 0; k < APL; ++k) {
         const int a = lane + k * LPG;
         if (a >= A) continue;
-        const double pr = R == 0 ? pa[k] / s : (ok[k] ? pa[k] : -1.0);
+        const double pr = R != 1 ? pa[k] / s : (ok[k] ? pa[k] : -1.0);
         double prior = pr;
         // optional root exploration noise (off by default; not in the reference's search, listed in its
         // src/deepmind_alphazero_pseudocode.py:285-290): prior*(1-eps) + noise*eps on the existing root children

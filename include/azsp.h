@@ -45,8 +45,12 @@ enum { AZSP_GAME_CONNECT4 = 0,   /* src/alphazero_simple/connect4_game.py:6-101 
  *   AZSP_RULES_GEN1    src/alphazero_implementation/core/search/mcts/search.py:10-91 + node.py:7-73: W float64,
  *                      score = W/n + c*P*sqrt(N)/(1+n) (no negation), priors taken as the model gives them, a child
  *                      for every legal action, the root's expansion is simulation 1 (so pi = n/(N-1)), no sign
- *                      flip above a terminal node.  Connect-4 only (the package hard-codes simulator.game.connect). */
-enum { AZSP_RULES_SIMPLE = 0, AZSP_RULES_GEN1 = 1 };
+ *                      flip above a terminal node.  Connect-4 only (the package hard-codes simulator.game.connect).
+ *   AZSP_RULES_SIMPLE_NUMPY1  AZSP_RULES_SIMPLE as the same source runs under numpy 1.x (requirements.txt does not
+ *                      pin numpy): `value_sum += np.float32` then promotes to float64, so W and -(W/n) are float64;
+ *                      everything else is unchanged.  numpy 1.x is not installable in the build environment: this
+ *                      variant is checked against the oracle's restatement only ("parity unpinned"). */
+enum { AZSP_RULES_SIMPLE = 0, AZSP_RULES_GEN1 = 1, AZSP_RULES_SIMPLE_NUMPY1 = 2 };
 
 /* Evaluator kinds: what stands behind BaseModel.predict (src/alphazero_simple/base_model.py:52-58). */
 enum { AZSP_EVAL_RESNET = 0,  /* on-device fp32 MFMA forward of ResNet (src/alphazero_simple/resnet.py:30-157) */

@@ -391,10 +391,13 @@ def masked_priors(p32, valid):                     # :119-121 and :165-167
 
 
 def run_batch(rules, predict: Callable, sims: int, states, to_plays, root_noise=None, noise_eps: float = 0.0,
-              c_of=None) -> list[ONode]:
+              c_of=None, numpy1: bool = False) -> list[ONode]:
     """monte_carlo_tree_search.py:111-171.  `root_noise` (array [n][A]) / `noise_eps` are an EXTENSION beyond the
     reference (off by default): root priors become prior*(1-eps) + noise*eps on existing children, the scheme of
-    the reference's src/deepmind_alphazero_pseudocode.py:285-290."""
+    the reference's src/deepmind_alphazero_pseudocode.py:285-290.
+    `numpy1=True` restates what the same source does under numpy 1.x (PARITY UNPINNED: numpy 1.x is not installed
+    here): `value_sum += np.float32` promotes to float64 there (pre-NEP-50 scalar promotion), modelled by widening
+    the network value to a Python float before it is added."""
     roots = []
     p_batch, _ = predict(states)                                   # :114 root values discarded
     for i, (st, tp, p) in enumerate(zip(states, to_plays, p_batch)):
@@ -425,7 +428,7 @@ def run_batch(rules, predict: Callable, sims: int, states, to_plays, root_noise=
             for (node, nxt), p, v in zip(pending, p_batch, v_batch):
                 par = node.up
                 node.grow(nxt, par.to_play * -1, masked_priors(p, rules.valid_moves(nxt)))
-                backup(node, v, par.to_play * -1)
+                backup(node, float(v) if numpy1 else v, par.to_play * -1)
     return roots
 
 
@@ -441,7 +444,8 @@ def root_counts(root: ONode, n_actions: int) -> list[int]:
 # --------------------------------------------------------------------------------------------
 def generate_episodes(rules, predict: Callable, sims: int, n_slots: int, rng=np.random,
                       trace: list | None = None, sampling_plies: int | None = None,
-                      dirichlet_alpha: float | None = None, dirichlet_eps: float = 0.25, c_of=None):
+                      dirichlet_alpha: float | None = None, dirichlet_eps: float = 0.25, c_of=None,
+                      numpy1: bool = False):
     """Yields episodes in the reference's (ply, slot) order; each episode is a list of
     (canonical_state int64, policy float64[A], value int).  ``trace`` (optional) receives one
     dict per (ply, slot) with the root visit counts and the chosen action.
@@ -459,7 +463,7 @@ def generate_episodes(rules, predict: Callable, sims: int, n_slots: int, rng=np.
     while True:                                                      # :30
         canon = [rules.canonical(s, p) for s, p in zip(states, players)]   # :31-34
         noise = rng.gamma(dirichlet_alpha, 1.0, (n_slots, A)) if dirichlet_alpha else None
-        roots = run_batch(rules, predict, sims, canon, players, noise, dirichlet_eps if dirichlet_alpha else 0.0, c_of)   # :36
+        roots = run_batch(rules, predict, sims, canon, players, noise, dirichlet_eps if dirichlet_alpha else 0.0, c_of, numpy1)   # :36
         for i in range(n_slots):                                     # :38-44 slot order = RNG order
             root = roots[i]
             counts = root_counts(root, A)

@@ -117,25 +117,30 @@ class _HostHashModel:
     """A gen-1 Model only reachable through .predict (State objects in, dicts out): exercises the host-callback
     evaluator and the state factory."""
 
-    def __init__(self, salt):
+    def __init__(self, salt, scale=None):
         self._m = g1.HashModelG1(salt)
         self.calls = 0
+        self.scale = scale
 
     def predict(self, states):
         self.calls += 1
-        return self._m.predict(states)
+        pols, vals = self._m.predict(states)
+        if self.scale is not None:       # full-mantissa float32 values (the hash values are multiples of 2^-15, whose
+            vals = [[float(np.float32(x) * np.float32(self.scale)) for x in v] for v in vals]   # sums are always exact)
+        return pols, vals
 
     def get_inference_clone(self):
         return self
 
 
-def test_gen1_host_model_predict_path(gen1):
+@pytest.mark.parametrize("scale,sims", [(None, 20), (0.7310586, 80)])
+def test_gen1_host_model_predict_path(gen1, scale, sims):
     from azsp import connect_state as cs
-    n, sims, seed = 6, 20, 4
+    n, seed = 6, 4
     np.random.seed(seed)
-    ref = list(g1.generate_episodes(g1.HashModelG1(2).predict, sims, n, g1.GConfig().sample_initial_state()))
+    ref = list(g1.generate_episodes(_HostHashModel(2, scale).predict, sims, n, g1.GConfig().sample_initial_state()))
     np.random.seed(seed)
-    model = _HostHashModel(2)
+    model = _HostHashModel(2, scale)
     gen = gen1.EpisodeGenerator(model=model, num_simulations=sims, num_episodes=n,
                                 game_initial_state=cs.Config().sample_initial_state())
     _compare_episodes(list(gen.generate_episodes()), ref)
@@ -224,3 +229,55 @@ def test_exploration_factor_option_bit_exact(c_init, c_base):
         assert [s.state.tolist() for s in ep.samples] == [np.asarray(s).tolist() for s, _, _ in r]
         assert [s.policy.tolist() for s in ep.samples] == [np.asarray(p).tolist() for _, p, _ in r]
         assert [s.value for s in ep.samples] == [int(z) for _, _, z in r]
+
+
+class _FullMantissaModel:
+    """The hash evaluator's values are multiples of 2^-15, whose sums are exact in float32 AND float64; scaling them
+    by an odd constant gives values that use the whole float32 mantissa, so the two accumulator widths diverge."""
+
+    def __init__(self, salt):
+        self._m = oz.HashModel(oz.C4Rules(), salt)
+
+    def predict(self, boards):
+        p, v = self._m.predict(boards)
+        return p, [np.float32(x) * np.float32(0.7310586) for x in v]
+
+
+def test_numpy1_value_sum_variant_bit_exact():
+    """AZSP_RULES_SIMPLE_NUMPY1: the alphazero_simple search with the float64 value sums numpy 1.x produces
+    (PARITY UNPINNED -- oracle restatement only).  The run must also differ somewhere from the float32 run, or the
+    variant would be vacuous."""
+    import azsp
+    from azsp.engine import Engine
+    n, sims, seed, salt = 16, 120, 5, 11
+    rules = oz.C4Rules()
+    model = _FullMantissaModel(salt)
+    np.random.seed(seed)
+    tr_wide, tr_f32 = [], []
+    ref = list(oz.generate_episodes(rules, model.predict, sims, n, numpy1=True, trace=tr_wide))
+    np.random.seed(seed)
+    list(oz.generate_episodes(rules, model.predict, sims, n, trace=tr_f32))
+    assert any(a["root_w"] != b["root_w"] for a, b in zip(tr_wide, tr_f32))
+    np.random.seed(seed)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1),
+                                numpy1_value_sums=True)
+    eps = list(gen.generate_episodes(model))
+    assert len(eps) == n
+    for ep, r in zip(eps, ref):
+        assert [s.state.tolist() for s in ep.samples] == [np.asarray(s).tolist() for s, _, _ in r]
+        assert [s.policy.tolist() for s in ep.samples] == [np.asarray(p).tolist() for _, p, _ in r]
+        assert [s.value for s in ep.samples] == [int(z) for _, _, z in r]
+    # value sums themselves: one batched search compared in float64, and against the float32 rule set
+    boards = [rules.init_board()] * 4
+    roots = oz.run_batch(rules, model.predict, sims, boards, [1] * 4, numpy1=True)
+    narrow = oz.run_batch(rules, model.predict, sims, boards, [1] * 4)
+    for rules_id, want in ((2, roots), (0, narrow)):
+        with Engine("connect4", 64, sims, search_rules=rules_id) as e:
+            e.use_host_evaluator(model.predict)
+            e.run_batch(np.stack(boards))
+            val = e.root_values(4)
+        for i, root in enumerate(want):
+            assert val["root_w"][i] == float(root.w) and val["root_n"][i] == root.n
+            for a, c in root.kids.items():
+                assert val["child_w"][i, a] == float(c.w)
+    assert any(float(a.w) != float(b.w) for a, b in zip(roots, narrow))
