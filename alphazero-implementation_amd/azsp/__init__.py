@@ -7,7 +7,7 @@ from .games import BaseGame, Connect2Game, Connect4Game, GomokuGame
 __all__ = ["AlphaZeroConfig", "Episode", "Sample", "BaseGame", "Connect2Game", "Connect4Game", "GomokuGame",
            "BaseModel", "ResNet", "MCTS", "Node", "EpisodeGenerator", "Engine", "generate_dataset",
            "DeviceReplayBuffer", "save_episodes", "load_episodes", "ShardedEpisodeGenerator",
-           "DistributedEpisodeGenerator"]
+           "DistributedEpisodeGenerator", "gen1", "connect_state"]
 
 
 def __getattr__(name):          # torch / libazsp are only imported when their classes are used
@@ -29,4 +29,7 @@ def __getattr__(name):          # torch / libazsp are only imported when their c
     if name in ("generate_dataset", "DeviceReplayBuffer", "save_episodes", "load_episodes"):
         from . import replay
         return getattr(replay, name)
+    if name in ("gen1", "connect_state"):     # first-generation surface (src/alphazero_implementation)
+        import importlib
+        return importlib.import_module("." + name, __name__)
     raise AttributeError(name)
