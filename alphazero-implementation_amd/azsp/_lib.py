@@ -14,6 +14,7 @@ GAME_CONNECT4, GAME_CONNECT2, GAME_GOMOKU9 = 0, 1, 2
 EVAL_RESNET, EVAL_HASH, EVAL_HOST = 0, 1, 2
 FLAG_TIMING = 1
 FLAG_F16_SPLIT = 2
+FLAG_TREE_REUSE = 4
 RULES_SIMPLE, RULES_GEN1, RULES_SIMPLE_NUMPY1 = 0, 1, 2
 ABI_VERSION = 2
 

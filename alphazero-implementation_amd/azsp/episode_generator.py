@@ -22,7 +22,7 @@ class EpisodeGenerator:
     def __init__(self, *, game, config: AlphaZeroConfig, device: int | None = None, timing: bool = False,
                  n_groups: int = 0, f16_split: bool = False, sampling_plies: int | None = None,
                  dirichlet_alpha: float | None = None, dirichlet_eps: float = 0.25, c_init: float = 1.0,
-                 c_base: float = 0.0, numpy1_value_sums: bool = False):
+                 c_base: float = 0.0, numpy1_value_sums: bool = False, tree_reuse: bool = False):
         self.game = game
         self.config = config
         self.device = device
@@ -35,6 +35,8 @@ class EpisodeGenerator:
         self.c_init, self.c_base = c_init, c_base
         # True: float64 value sums, the arithmetic the reference's source has under numpy 1.x (AZSP_RULES_SIMPLE_NUMPY1)
         self.numpy1_value_sums = numpy1_value_sums
+        # True: keep the chosen child's subtree (and its statistics) as the next ply's tree (AZSP_FLAG_TREE_REUSE)
+        self.tree_reuse = tree_reuse
         self.f16_split = f16_split    # device ResNet on the fp16 matrix pipe with split operands (fp32-class accuracy)
         self.n_groups = n_groups      # concurrent slot groups (HIP streams); 0 = automatic; never changes results
         self._engine: Engine | None = None
@@ -43,7 +45,7 @@ class EpisodeGenerator:
 
     def engine_for(self, model) -> Engine:
         blocks, ch, salt = engine_geometry_for_model(model, self.game)
-        key = (self.config.num_episodes, self.config.num_simulations, blocks, ch, salt, self.f16_split, self.numpy1_value_sums)
+        key = (self.config.num_episodes, self.config.num_simulations, blocks, ch, salt, self.f16_split, self.numpy1_value_sums, self.tree_reuse)
         if self._engine is None or key != self._engine_key:
             if self._engine is not None:
                 self._engine.close()
@@ -51,7 +53,7 @@ class EpisodeGenerator:
             self._engine = Engine(self.game, self.config.num_episodes, self.config.num_simulations, device=dev,
                                   res_blocks=blocks, channels=ch, timing=self.timing, hash_salt=salt,
                                   n_groups=self.n_groups, f16_split=self.f16_split,
-                                  search_rules=2 if self.numpy1_value_sums else 0)
+                                  search_rules=2 if self.numpy1_value_sums else 0, tree_reuse=self.tree_reuse)
             self._engine_key = key
         configure_engine_for_model(self._engine, model)
         return self._engine

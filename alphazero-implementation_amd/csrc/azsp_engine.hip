@@ -91,6 +91,7 @@ struct azsp_engine {
     double *d_st_wd = nullptr, *d_st_rwd = nullptr;   // float64 root statistics staging
     double *d_sqrt = nullptr, *d_ctab = nullptr, *d_expl = nullptr;   // [n_sims + 2] exploration tables
     double c_init = 1.0, c_base = 0.0;
+    int tab_len = 0;
     std::vector<int8_t> h_cells;
     std::vector<float> h_p, h_v, h_p8;
     std::vector<u64> h_mine, h_theirs;
@@ -348,10 +349,10 @@ void azsp_destroy(azsp_engine *e) {
     delete e;
 }
 
-// sqrt(N), c(N) and c(N)*sqrt(N) for N = 0 .. n_sims+1, computed on the host: libm's sqrt/log are what
+// sqrt(N), c(N) and c(N)*sqrt(N) for N = 0 .. tab_len-1, computed on the host: libm's sqrt/log are what
 // Python's math.sqrt/math.log call, so the tables are bit-identical to the reference's per-call values.
 static int upload_exploration_tables(azsp_engine *e) {
-    const int n = e->cfg.n_sims + 2;
+    const int n = e->tab_len;
     std::vector<double> sq(n), ct(n), ex(n);
     for (int i = 0; i < n; ++i) {
         sq[i] = sqrt((double)i);
@@ -389,22 +390,27 @@ static int create_impl(azsp_engine *e) {
     v.grp = 0;
     v.A = A;
     v.n_sims = S;
-    v.E = S + 1;
-    v.C = ((1 + A * (S + 1)) + 7) & ~7;
-    v.D = (S + 2 < gi.max_plies + 2) ? S + 2 : gi.max_plies + 2;
+    // expansions per tree: one root + one per simulation; with tree reuse a tree lives for a whole game
+    v.reuse = (c.flags & AZSP_FLAG_TREE_REUSE) ? 1 : 0;
+    v.E = v.reuse ? (S + 1) * gi.max_plies : S + 1;
+    v.C = ((1 + A * v.E) + 7) & ~7;
+    v.D = (!v.reuse && S + 2 < gi.max_plies + 2) ? S + 2 : gi.max_plies + 2;
     v.max_plies = gi.max_plies;
     v.cells = gi.cells;
     const size_t NC = (size_t)N * v.C, NE = (size_t)N * v.E;
     DEV_ALLOC(v.cnt, NC); DEV_ALLOC(v.wsum, NC); DEV_ALLOC(v.prior, NC); DEV_ALLOC(v.kids, NC);
     DEV_ALLOC(v.blk_parent, NE); DEV_ALLOC(v.st_mine, NE * W); DEV_ALLOC(v.st_theirs, NE * W);
-    DEV_ALLOC(v.n_blk, N);
+    DEV_ALLOC(v.n_blk, N); DEV_ALLOC(v.root, N); DEV_ALLOC(v.next_root, N);
+    HIP_TRY(hipMemset(v.root, 0, (size_t)N * sizeof(int32_t)));
+    HIP_TRY(hipMemset(v.next_root, 0xff, (size_t)N * sizeof(int32_t)));
     DEV_ALLOC(v.path, (size_t)N * v.D); DEV_ALLOC(v.path_len, N); DEV_ALLOC(v.leaf_node, N);
     DEV_ALLOC(v.leaf_mine, (size_t)N * W); DEV_ALLOC(v.leaf_theirs, (size_t)N * W); DEV_ALLOC(v.pending, N);
     DEV_ALLOC(v.leaf_slot, N); DEV_ALLOC(v.n_leaf, MAX_GROUPS);
     HIP_TRY(hipMemset(v.leaf_slot, 0, (size_t)N * sizeof(int32_t)));
     HIP_TRY(hipMemset(v.n_leaf, 0, MAX_GROUPS * sizeof(int32_t)));
     DEV_ALLOC(v.eval_p, (size_t)N * AP); DEV_ALLOC(v.eval_v, N);
-    DEV_ALLOC(e->d_sqrt, S + 2); DEV_ALLOC(e->d_ctab, S + 2); DEV_ALLOC(e->d_expl, S + 2);
+    e->tab_len = v.reuse ? (S + 1) * gi.max_plies + 2 : S + 2;    // largest N_parent + 1 a search can see
+    DEV_ALLOC(e->d_sqrt, e->tab_len); DEV_ALLOC(e->d_ctab, e->tab_len); DEV_ALLOC(e->d_expl, e->tab_len);
     v.sqrt_tab = e->d_sqrt;
     v.c_tab = e->d_ctab;
     v.expl_tab = e->d_expl;
@@ -466,6 +472,10 @@ int azsp_create(const azsp_config *cfg, azsp_engine **out) {
         return fail(AZSP_ERR_ARG, "unknown search rule set %d", cfg->search_rules);
     if (cfg->search_rules == AZSP_RULES_GEN1 && cfg->game != AZSP_GAME_CONNECT4)
         return fail(AZSP_ERR_ARG, "AZSP_RULES_GEN1 is defined for Connect-4 only");
+    if (cfg->search_rules == AZSP_RULES_GEN1 && (cfg->flags & AZSP_FLAG_TREE_REUSE))
+        return fail(AZSP_ERR_ARG, "AZSP_FLAG_TREE_REUSE is defined for the alphazero_simple rule sets only");
+    if ((cfg->flags & AZSP_FLAG_TREE_REUSE) && (long long)gi.A * (cfg->n_sims + 1) * gi.max_plies > (1ll << 30))
+        return fail(AZSP_ERR_ARG, "tree reuse: %d sims x %d plies x %d actions exceeds the node index range", cfg->n_sims, gi.max_plies, gi.A);
     if (cfg->search_rules == AZSP_RULES_GEN1 && cfg->n_sims < 1)
         return fail(AZSP_ERR_ARG, "AZSP_RULES_GEN1 needs n_sims >= 1 (the root expansion is simulation 1)");
     int ndev = 0;

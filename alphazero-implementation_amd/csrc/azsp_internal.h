@@ -12,7 +12,7 @@ constexpr int MAX_GROUPS = 8; // slot groups searched concurrently on separate H
 
 // Device-resident state of one engine.  Structure-of-arrays; every per-node array is [slot][C].
 //
-//   node 0            root
+//   node 0            root (of a fresh tree; with tree reuse root[slot] walks down the same arrays)
 //   node 1 + e*A + a  child for action a of the e-th expanded node of this tree ("block" e);
 //                     blocks are bump-allocated in expansion order (deterministic).
 //   kids[x]           first child of x (1 + e*A), 0 while x is unexpanded
@@ -31,6 +31,7 @@ struct View {
     int32_t max_plies; // history capacity per slot
     int32_t cells;
     int32_t rules;     // AZSP_RULES_*: which of the reference's two search rule sets the kernels follow
+    int32_t reuse;     // AZSP_FLAG_TREE_REUSE: the chosen child's subtree becomes the next ply's tree
 
     // search tree (SoA)
     int32_t *cnt;       // N  visit_count                       [n_slots][C]
@@ -41,6 +42,8 @@ struct View {
     int32_t *blk_parent;    // [n_slots][E]
     u64     *st_mine, *st_theirs;   // [n_slots][E][W]   (W = 64-bit words per side, from the game trait)
     int32_t *n_blk;         // [n_slots]
+    int32_t *root;          // [n_slots] node index of the current root (0 unless the tree is being reused)
+    int32_t *next_root;     // [n_slots] child chosen by k_finish, or -1: the next search starts a fresh tree
     // per-round scratch
     int32_t *path;          // [n_slots][D]  root .. leaf of the current descent
     int32_t *path_len;      // [n_slots]     0 for a root expansion (no backup)
@@ -51,7 +54,7 @@ struct View {
     int32_t *n_leaf;        // [MAX_GROUPS]
     float   *eval_p;        // [n_slots][AP] evaluator output (AP = A padded to 8), at offset lo, indexed by compacted leaf
     float   *eval_v;        // [n_slots]
-    const double *sqrt_tab; // [n_sims + 2] host-computed sqrt(N): bit-identical to math.sqrt
+    const double *sqrt_tab; // [n_sims + 2, or a whole game's simulations with tree reuse] host-computed sqrt(N): bit-identical to math.sqrt
     const double *c_tab;    // [n_sims + 2] exploration factor c(N): 1.0 unless options say otherwise
     const double *expl_tab; // [n_sims + 2] c(N) * sqrt(N)  (== sqrt_tab bit for bit while c == 1)
     // search options beyond the reference (all off by default)

@@ -74,14 +74,29 @@ __global__ void k_root_prepare(View v) {
     if (g >= v.n_act) return;
     g += v.lo;
     size_t base = (size_t)g * v.C;
-    v.cnt[base] = 0;
-    if constexpr (R == 0) v.wsum[base] = 0.0f; else v.wsum_d[base] = 0.0;
-    v.kids[base] = 0;
-    v.prior[base] = 0.0;
-    v.n_blk[g] = 0;
+    int root = 0;
+    if (v.reuse) {
+        // tree reuse (not in the reference, which rebuilds its trees every ply): the child chosen by the last
+        // k_finish becomes the root with everything below it; blocks keep being bump-allocated after the old ones
+        const int nr = v.next_root[g];
+        v.next_root[g] = -1;
+        if (nr > 0) {
+            v.root[g] = nr;
+            if (v.kids[base + nr] != 0) { v.pending[g] = 0; return; }      // expanded: nothing to evaluate
+            root = nr;                                                      // never visited: expand it as a root
+        } else {
+            v.n_blk[g] = 0;
+            v.root[g] = 0;
+        }
+    } else {
+        v.n_blk[g] = 0;
+    }
+    v.cnt[base + root] = 0;
+    if constexpr (R == 0) v.wsum[base + root] = 0.0f; else v.wsum_d[base + root] = 0.0;
+    v.kids[base + root] = 0;
     if constexpr (R != 1) v.path_len[g] = 0;       // run_batch :112-123: the root value is discarded
-    else { v.path_len[g] = 1; v.path[(size_t)g * v.D] = 0; }   // search.py:72-91: expanding the root IS simulation 1
-    v.leaf_node[g] = 0;
+    else { v.path_len[g] = 1; v.path[(size_t)g * v.D] = root; }   // search.py:72-91: expanding the root IS simulation 1
+    v.leaf_node[g] = root;
     board_store<G::W>(v.leaf_mine, g, board_load<G::W>(v.cur_mine, g));
     board_store<G::W>(v.leaf_theirs, g, board_load<G::W>(v.cur_theirs, g));
     v.pending[g] = 1;
@@ -107,11 +122,15 @@ __global__ __launch_bounds__(64) void k_select(View v) {
     int *my_path = s_path + grp * v.D;
 
     // One dependent round trip per tree level: the lanes fetch N, W, P AND the first-child index of their
-    // children together; the chosen child's first-child index then comes from a shuffle, and N_parent is not
-    // loaded but rebuilt from the children (an expanded node is visited once at expansion and afterwards
-    // only on the way to one of its children: N = 1 + sum N_child; the root is never counted at expansion).
-    int node = 0, depth = 0, parent_fc = 0, action = 0;
-    int fc = live ? v.kids[base] : 0;
+    // children together; the chosen child's first-child index then comes from a shuffle, and below the root
+    // N_parent is not loaded but rebuilt from the children (an expanded node is visited once at expansion and
+    // afterwards only on the way to one of its children: N = 1 + sum N_child).  The root's own count is read
+    // up front, next to its first-child index (no dependency): whether it was counted at its expansion differs
+    // between the rule sets and for a reused subtree.
+    const int root = live ? (v.reuse ? v.root[g] : 0) : 0;
+    int node = root, depth = 0, parent_fc = 0, action = 0;
+    int fc = live ? v.kids[base + root] : 0;
+    const int n_root = live ? v.cnt[base + root] : 0;
     bool walking = live;
     while (true) {
         walking = walking && fc != 0;               // Node.expanded() :35-36
@@ -131,8 +150,8 @@ __global__ __launch_bounds__(64) void k_select(View v) {
             kc[k] = in ? v.kids[base + child] : 0;
             nsum += n[k];
         }
-        // rule set 1: the root too is counted at its expansion (search.py:72-91)
-        const int np_ = red_add<LPG>(nsum) + (R == 1 || node != 0);
+        const int nkids = red_add<LPG>(nsum);
+        const int np_ = node == root ? n_root : nkids + 1;
         double score = -INFINITY;
         int best = lane;
 #pragma unroll
@@ -335,7 +354,7 @@ __global__ __launch_bounds__(64) void k_expand(View v) {
         double prior = pr;
         // optional root exploration noise (off by default; not in the reference's search, listed in its
         // src/deepmind_alphazero_pseudocode.py:285-290): prior*(1-eps) + noise*eps on the existing root children
-        if (node == 0 && v.root_noise != nullptr && child_exists<R>(pr))
+        if (L == (R == 1 ? 1 : 0) && v.root_noise != nullptr && child_exists<R>(pr))      // a root expansion
             prior = pr * v.noise_keep + v.root_noise[(size_t)g * A + a] * v.noise_eps;
         v.cnt[base + fc + a] = 0;                   // Node.expand :80-90
         wsum[base + fc + a] = (WT)0;
@@ -387,14 +406,15 @@ __global__ __launch_bounds__(64) void k_finish(View v, const double *uniforms) {
     const size_t base = (size_t)g * v.C;
     const int len = v.cur_len[g];
     const size_t h = (size_t)g * v.max_plies + len;
+    const int rfc = live ? v.kids[base + (v.reuse ? v.root[g] : 0)] : 1;     // the root's children
 #pragma unroll
     for (int k = 0; k < APL; ++k) {
         const int a = lane + k * LPG;
         if (a >= G::AP) continue;
         int c = 0, ex = 0;
         if (live && a < A) {
-            ex = child_exists<R>(v.prior[base + 1 + a]);      // root.children keys
-            c = ex ? v.cnt[base + 1 + a] : 0;
+            ex = child_exists<R>(v.prior[base + rfc + a]);      // root.children keys
+            c = ex ? v.cnt[base + rfc + a] : 0;
         }
         s_cnt[grp][a] = c;
         s_ex[grp][a] = (unsigned char)ex;
@@ -439,6 +459,7 @@ __global__ __launch_bounds__(64) void k_finish(View v, const double *uniforms) {
     v.cur_len[g] = len + 1;
     v.chosen[g] = act;
     v.h_action[h] = (uint8_t)act;
+    if (v.reuse) v.next_root[g] = term == TERM_NONE ? rfc + act : -1;
     v.done[g] = term != TERM_NONE;
     v.reward[g] = (int8_t)(term == TERM_NONE ? 0 : term);
 }
@@ -586,6 +607,7 @@ __global__ void k_reset_slots(View v) {
     v.cur_len[g] = 0;
     v.done[g] = 0;
     v.pending[g] = 0;
+    if (v.reuse) { v.next_root[g] = -1; v.root[g] = 0; }
 }
 
 template <class G>
@@ -595,6 +617,7 @@ __global__ void k_set_boards(View v, const u64 *mine, const u64 *theirs, int n) 
     board_store<G::W>(v.cur_mine, g, board_load<G::W>(mine, g));
     board_store<G::W>(v.cur_theirs, g, board_load<G::W>(theirs, g));
     v.cur_len[g] = 0;
+    if (v.reuse) v.next_root[g] = -1;
 }
 
 template <class G, int R>
@@ -603,11 +626,12 @@ __global__ void k_root_stats(View v, int32_t *counts, float *child_w, double *pr
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.n_act * G::A) return;
     const int g = i / G::A, a = i % G::A;
-    const size_t base = (size_t)g * v.C;
-    const double p = v.prior[base + 1 + a];
+    const size_t base = (size_t)g * v.C + (v.reuse ? v.root[g] : 0);      // the root node
+    const int rfc = v.kids[base] - (v.reuse ? v.root[g] : 0);             // its children, relative to it
+    const double p = v.prior[base + rfc + a];
     const bool ex = child_exists<R>(p);
-    const double w = ex ? (R == 0 ? (double)v.wsum[base + 1 + a] : v.wsum_d[base + 1 + a]) : 0.0;
-    if (counts) counts[i] = ex ? v.cnt[base + 1 + a] : 0;
+    const double w = ex ? (R == 0 ? (double)v.wsum[base + rfc + a] : v.wsum_d[base + rfc + a]) : 0.0;
+    if (counts) counts[i] = ex ? v.cnt[base + rfc + a] : 0;
     if (child_w) child_w[i] = (float)w;
     if (child_wd) child_wd[i] = w;
     if (prior) prior[i] = ex ? p : 0.0;

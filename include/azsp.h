@@ -66,6 +66,13 @@ enum { AZSP_OK = 0, AZSP_ERR_ARG = -1, AZSP_ERR_HIP = -2, AZSP_ERR_STATE = -3, A
                                     accuracy (<= 1e-5 on p, v), 3 MFMAs at 16x the fp32-MFMA rate.  Without
                                     the flag the network runs on v_mfma_f32_32x32x2_f32 (exact fp32).     */
 
+#define AZSP_FLAG_TREE_REUSE 4u  /* NOT in the reference (it rebuilds every tree every ply, monte_carlo_tree_search.py:116-123;
+                                    listed as an option in SURVEY 8f): after a move the chosen child's subtree, with
+                                    its statistics, is the next ply's tree and n_sims further simulations are added
+                                    to it.  Trees then live for a whole game: node capacity per slot grows from
+                                    A*(n_sims+1) to A*(n_sims+1)*max_plies (HBM is sized for it).  Root noise is only
+                                    mixed in where a root is expanded afresh.                                   */
+
 typedef struct azsp_config {
     uint32_t struct_size;    /* sizeof(azsp_config), for forward compatibility                       */
     int32_t  game;           /* AZSP_GAME_*                                                           */

@@ -391,23 +391,31 @@ def masked_priors(p32, valid):                     # :119-121 and :165-167
 
 
 def run_batch(rules, predict: Callable, sims: int, states, to_plays, root_noise=None, noise_eps: float = 0.0,
-              c_of=None, numpy1: bool = False) -> list[ONode]:
+              c_of=None, numpy1: bool = False, roots_in=None) -> list[ONode]:
     """monte_carlo_tree_search.py:111-171.  `root_noise` (array [n][A]) / `noise_eps` are an EXTENSION beyond the
     reference (off by default): root priors become prior*(1-eps) + noise*eps on existing children, the scheme of
     the reference's src/deepmind_alphazero_pseudocode.py:285-290.
     `numpy1=True` restates what the same source does under numpy 1.x (PARITY UNPINNED: numpy 1.x is not installed
     here): `value_sum += np.float32` promotes to float64 there (pre-NEP-50 scalar promotion), modelled by widening
-    the network value to a Python float before it is added."""
-    roots = []
-    p_batch, _ = predict(states)                                   # :114 root values discarded
-    for i, (st, tp, p) in enumerate(zip(states, to_plays, p_batch)):
+    the network value to a Python float before it is added.
+    `roots_in` (EXTENSION, tree reuse): per slot an already expanded node to continue from, or None for a fresh root."""
+    roots = [None] * len(states)
+    fresh = list(range(len(states)))
+    if roots_in is not None:
+        fresh = [i for i, r in enumerate(roots_in) if r is None or not r.is_expanded()]
+        for i, r in enumerate(roots_in):
+            if r is not None and r.is_expanded():
+                roots[i] = r
+    p_batch = predict([states[i] for i in fresh])[0] if fresh else []   # :114 root values discarded
+    for i, p in zip(fresh, p_batch):
+        st, tp = states[i], to_plays[i]
         root = ONode(0, tp)
         pr = masked_priors(p, rules.valid_moves(st))
         if root_noise is not None:
             keep = 1.0 - noise_eps
             pr = np.array([x * keep + root_noise[i][a] * noise_eps if x != 0 else 0.0 for a, x in enumerate(pr)])
         root.grow(st, tp, pr)                                       # :116-123
-        roots.append(root)
+        roots[i] = root
 
     for _ in range(sims):                                           # :125
         pending = []
@@ -445,7 +453,7 @@ def root_counts(root: ONode, n_actions: int) -> list[int]:
 def generate_episodes(rules, predict: Callable, sims: int, n_slots: int, rng=np.random,
                       trace: list | None = None, sampling_plies: int | None = None,
                       dirichlet_alpha: float | None = None, dirichlet_eps: float = 0.25, c_of=None,
-                      numpy1: bool = False):
+                      numpy1: bool = False, reuse: bool = False):
     """Yields episodes in the reference's (ply, slot) order; each episode is a list of
     (canonical_state int64, policy float64[A], value int).  ``trace`` (optional) receives one
     dict per (ply, slot) with the root visit counts and the chosen action.
@@ -453,17 +461,21 @@ def generate_episodes(rules, predict: Callable, sims: int, n_slots: int, rng=np.
     EXTENSIONS beyond the reference (None = reference behaviour; they define what the engine's options must do):
     `sampling_plies`: from that ply of a game on the move is select_action(temperature=0) (mcts:49-50); the
     slot's uniform is still drawn so the stream stays aligned.  `dirichlet_alpha`: per ply, before the search,
-    rng.gamma(alpha, 1, (n_slots, A)) is drawn and mixed into the root priors with weight `dirichlet_eps`."""
+    rng.gamma(alpha, 1, (n_slots, A)) is drawn and mixed into the root priors with weight `dirichlet_eps`.
+    `reuse`: after a move that does not end the game the chosen child, with everything below it, is the next ply's
+    root (its `up` link is cut, so backups stop there) and `sims` further simulations are added to it."""
     A = rules.action_size
     states = [rules.init_board() for _ in range(n_slots)]            # :25
     players = [1] * n_slots                                          # :26
     hist: list[list] = [[] for _ in range(n_slots)]                  # :27
     done = 0
     ply = 0
+    keep = [None] * n_slots
     while True:                                                      # :30
         canon = [rules.canonical(s, p) for s, p in zip(states, players)]   # :31-34
         noise = rng.gamma(dirichlet_alpha, 1.0, (n_slots, A)) if dirichlet_alpha else None
-        roots = run_batch(rules, predict, sims, canon, players, noise, dirichlet_eps if dirichlet_alpha else 0.0, c_of, numpy1)   # :36
+        roots = run_batch(rules, predict, sims, canon, players, noise, dirichlet_eps if dirichlet_alpha else 0.0, c_of, numpy1,
+                          keep if reuse else None)                                                      # :36
         for i in range(n_slots):                                     # :38-44 slot order = RNG order
             root = roots[i]
             counts = root_counts(root, A)
@@ -479,6 +491,10 @@ def generate_episodes(rules, predict: Callable, sims: int, n_slots: int, rng=np.
             if trace is not None:
                 trace.append({"ply": ply, "slot": i, "counts": counts, "action": int(act),
                               "root_w": float(root.w), "root_n": int(root.n)})
+            keep[i] = None
+            if reuse and rew is None:
+                keep[i] = root.kids[act]
+                keep[i].up = None
             if rew is not None:                                      # :61
                 ep = [(s, pi_k, rew * ((-1) ** (pl != players[i])))  # :63-76
                       for s, pl, pi_k in hist[i]]

@@ -281,3 +281,42 @@ def test_numpy1_value_sum_variant_bit_exact():
             for a, c in root.kids.items():
                 assert val["child_w"][i, a] == float(c.w)
     assert any(float(a.w) != float(b.w) for a, b in zip(roots, narrow))
+
+
+# ------------------------------------------------------------------------------------ tree reuse (option beyond the reference)
+@pytest.mark.parametrize("n,sims,seed,extra", [(8, 30, 1, {}), (32, 100, 2, {}), (6, 3, 3, {}), (16, 60, 4, {"c_init": 1.4}),
+                                               (12, 40, 5, {"dirichlet_alpha": 0.5, "dirichlet_eps": 0.25})])
+def test_tree_reuse_option_bit_exact(n, sims, seed, extra):
+    """AZSP_FLAG_TREE_REUSE: the chosen child's subtree (visit counts, value sums, priors, everything below) is
+    the next ply's tree.  The reference rebuilds its trees (monte_carlo_tree_search.py:116-123), so this is pinned
+    against the oracle's documented extension; slot restarts must start from a fresh tree, trees must survive
+    across plies in place (node indices keep growing), and the run must differ from the non-reusing one."""
+    import azsp
+    from helpers import HashStub
+    salt = 13
+    rules = oz.C4Rules()
+    okw = dict(extra)
+    if "c_init" in okw:
+        okw = {"c_of": oz.exploration_factor(okw["c_init"], 0.0)}
+    np.random.seed(seed)
+    tr = []
+    ref = list(oz.generate_episodes(rules, oz.HashModel(rules, salt).predict, sims, n, reuse=True, trace=tr, **okw))
+    after = float(np.random.random_sample())
+    assert max(sum(t["counts"]) for t in tr) > sims            # reused roots carry visits over
+    np.random.seed(seed)
+    plain = list(oz.generate_episodes(rules, oz.HashModel(rules, salt).predict, sims, n, **okw))
+    assert [[p.tolist() for _, p, _ in e] for e in plain] != [[p.tolist() for _, p, _ in e] for e in ref]
+    np.random.seed(seed)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1),
+                                tree_reuse=True, **extra)
+    eps = list(gen.generate_episodes(HashStub("connect4", salt)))
+    assert float(np.random.random_sample()) == after
+    assert len(eps) == n
+    for ep, r in zip(eps, ref):
+        assert [s.state.tolist() for s in ep.samples] == [np.asarray(s).tolist() for s, _, _ in r]
+        assert [s.policy.tolist() for s in ep.samples] == [np.asarray(p).tolist() for _, p, _ in r]
+        assert [s.value for s in ep.samples] == [int(z) for _, _, z in r]
+    # the same engine again: every slot starts from a fresh tree after reset()
+    np.random.seed(seed)
+    eps2 = list(gen.generate_episodes(HashStub("connect4", salt)))
+    assert [[s.policy.tolist() for s in e.samples] for e in eps2] == [[s.policy.tolist() for s in e.samples] for e in eps]
