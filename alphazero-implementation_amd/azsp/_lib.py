@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libazsp.so")
+# AZSP_LIB: another build of the same library (A/B timing of kernel variants on one box); default = the in-tree build
+LIB_PATH = os.environ.get("AZSP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libazsp.so")
 
 GAME_CONNECT4, GAME_CONNECT2, GAME_GOMOKU9 = 0, 1, 2
 EVAL_RESNET, EVAL_HASH, EVAL_HOST = 0, 1, 2

@@ -19,9 +19,11 @@
 //     order, then masked softmax / tanh.  Every board's result is independent of which tile /
 //     row it landed in (batch-invariant), so leaf order does not influence the search.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "azsp_internal.h"
@@ -30,6 +32,7 @@
 namespace azsp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
 struct NetGeom {
@@ -44,16 +47,20 @@ struct ResNetDev {
     float *d_blob = nullptr;   // all permuted parameters
     size_t blob_floats = 0;
     // offsets (in floats) into d_blob
-    size_t o_stem_w, o_stem_b, o_conv_w, o_conv_b, o_pol_w, o_pol_b, o_val_w, o_val_b, o_fcp_w, o_fcp_b, o_fcv_w, o_fcv_b;
+    size_t o_stem_w, o_stem_b, o_conv_w, o_conv_b, o_pol_w, o_pol_b, o_val_w, o_val_w4, o_val_b, o_fcp_w, o_fcp_b, o_fcv_w, o_fcv_b;
     size_t conv_w_stride, conv_b_stride;
     double flops_per_board = 0;
     ResNet16Dev *f16 = nullptr;   // split-fp16 variant (AZSP_FLAG_F16_SPLIT)
 };
 
 struct NetParams {
-    const float *stem_w, *stem_b, *conv_w, *conv_b, *pol_w, *pol_b, *val_w, *val_b, *fcp_w, *fcp_b, *fcv_w, *fcv_b;
+    const float *stem_w, *stem_b, *conv_w, *conv_b, *pol_w, *pol_b, *val_w, *val_w4, *val_b, *fcp_w, *fcp_b, *fcv_w, *fcv_b;
     int conv_w_stride, conv_b_stride, blocks;
+    unsigned long long *dbg;      // diagnostic phase timestamps (AZSP_RESNET_TRACE), else nullptr
 };
+// phase timestamp of wave 0 of each workgroup, 100 MHz constant clock; compiled only into the TR = true
+// diagnostic instantiation (AZSP_RESNET_TRACE), the product kernels carry no stamp code
+#define STAMP(k) do { if constexpr (TR) { if (tid == 0) P.dbg[(size_t)blockIdx.x * 64 + (k)] = wall_clock64(); } } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
@@ -158,7 +165,7 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
 //   row = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5),  col = l & 31
 __device__ __forceinline__ int cd_row(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
 
-template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4>
+template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4, bool TR = false>
 __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 && NT <= 2 ? 3 : (RW * CW > 8 ? RW * CW / 4 : 2))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
                                                          const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
                                                          float *__restrict__ out_p, float *__restrict__ out_v) {
@@ -184,6 +191,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     const int wave = (tid >> 6) / CW, wc = (tid >> 6) % CW;    // row group, column group
     const int col0 = wc * NTW * 32;
 
+    STAMP(0);
     for (int i = tid; i < STRIDE; i += NTHREADS) act[ZERO_IDX + i] = 0.0f;
 
     // ---- per-lane row geometry -------------------------------------------------------------------
@@ -217,6 +225,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     }
 
     f32x16 acc[MT][NTW], xres[MT][NTW];
+    STAMP(1);
 
     // ---- stem: conv3x3(3 -> C) + BN + ReLU, A fragments generated from the bitboards ---------------
     // (_states_to_tensor resnet.py:115-128: planes [empty, mine(+1), theirs(-1)]; input_conv :44-48)
@@ -265,6 +274,8 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
                 }
     }
     __syncthreads();
+    STAMP(2);
+    if constexpr (TR) { if (tid == 0) P.dbg[(size_t)blockIdx.x * 64 + 56] = __builtin_amdgcn_s_memtime(); }   // core-clock counter
 
     // ---- residual blocks (ResBlock.forward resnet.py:21-27) -----------------------------------------
     for (int layer = 0; layer < 2 * P.blocks; ++layer) {
@@ -280,7 +291,9 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
                 for (int v = 0; v < 16; ++v) acc[mt][nt][v] = second ? xres[mt][nt][v] + bias : bias;   // x += residual
         }
         conv_mfma<G, MT, NTW, 9, S, PF, NT>(acc, wl + wc * NTW, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
+        if (layer < 16) STAMP(3 + 3 * layer);
         __syncthreads();                               // every wave is done reading the layer input
+        if (layer < 16) STAMP(4 + 3 * layer);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -292,8 +305,15 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
                     act[(wave * WROWS + mt * 32 + cd_row(v, lane)) * STRIDE + col0 + nt * 32 + (lane & 31)] = o;
                 }
         __syncthreads();
+        if (layer < 16) STAMP(5 + 3 * layer);
     }
 
+    if constexpr (TR) {
+        if (tid == 0) {
+            P.dbg[(size_t)blockIdx.x * 64 + 57] = __builtin_amdgcn_s_memtime();
+            P.dbg[(size_t)blockIdx.x * 64 + 58] = wall_clock64();
+        }
+    }
     // ---- heads: policy conv1x1(C->32)+BN+ReLU (resnet.py:56-59), value conv3x3(C->3)+BN+ReLU (:65-68)
     f32x16 accp[MT][1];
     {
@@ -305,12 +325,65 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     }
     if (wc == 0)      // one 32-channel tile: the first column wave of each row group computes it
         conv_mfma<G, MT, 1, 1, S, PF>(accp, P.pol_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
-    // The value conv has 3 output channels: on the matrix pipe it would be padded to a 32-wide tile
-    // (+5.8 % MFMA time for 0.6 % of the FLOPs), so it runs on the vector ALU instead -- one thread per
-    // board cell, weights wave-uniform (scalar loads), activations read conflict-free from LDS --
-    // where it overlaps with the other resident workgroups' MFMA phases.
+    STAMP(51);
+    // The value conv has 3 output channels.  As a 32-wide MFMA tile it would cost +5.8 % MFMA time for 0.6 % of the
+    // FLOPs; on the vector ALU it took 16 us of a 370 us workgroup (scalar weight loads and LDS reads sharing one
+    // wait counter).  It runs on v_mfma_f32_4x4x1_16B_f32 instead: 16 independent 4x4 blocks per instruction, a
+    // block = 4 board cells x 4 output channels (3 real), K = 1, so 64 cells advance one input channel per 8-cycle
+    // instruction; every cell's sum is a fixed-order fma chain per kernel row (batch-invariant).
+    // Operand layout (probed on gfx950): A row i of block b from lane 4b+i, B column j from lane 4b+j,
+    // D[i][j] in VGPR i of lane 4b+j.
+    constexpr bool VMFMA = (CW == 1) && ((RW * MT) % 2 == 0);
     float hv0 = 0.0f, hv1 = 0.0f, hv2 = 0.0f;
-    if (tid < TB * CELLS) {
+    if constexpr (VMFMA) {
+        constexpr int NCHUNK = WG_ROWS / 64;           // 64-row chunks; wave w owns chunk w
+        const int wv = tid >> 6;
+        if (wv < NCHUNK) {
+            const int r = wv * 64 + lane;
+            const int pos = r % CELLS, y = pos / COLS, x = pos % COLS;
+            const bool real = r < TB * CELLS && board0 + r / CELLS < n_leaf;
+            const int j = lane & 3;
+            const float bj = j < VAL_CH ? P.val_b[j] : 0.0f;
+            // three independent accumulation chains, one per kernel row (dy = -1, 0, +1), summed at the end in a
+            // fixed order: dependent 4x4x1 MFMAs issue only every ~4 passes, independent ones back to back
+            f32x4 ar[3] = {{bj, bj, bj, bj}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            const float *xr[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                const bool ok = real && yy >= 0 && yy < ROWS && xx >= 0 && xx < COLS;
+                xr[t] = act + (ok ? (r + (t / 3 - 1) * COLS + (t % 3 - 1)) * STRIDE : ZERO_IDX);
+            }
+            const float *wt = P.val_w4 + j * 4;                                // [tap][c / 4][j][c % 4]
+            for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll 2
+                for (int c = 0; c < CP; c += 4) {
+                    float4 w[3];
+                    const float *a[3];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        w[dy] = *reinterpret_cast<const float4 *>(wt + ((size_t)(dy * 3 + dx) * CP + c) * 4);
+                        a[dy] = dx == 0 ? xr[dy * 3] : (dx == 1 ? xr[dy * 3 + 1] : xr[dy * 3 + 2]);
+                    }
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) ar[dy] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[dy][c + 0], w[dy].x, ar[dy], 0, 0, 0);
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) ar[dy] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[dy][c + 1], w[dy].y, ar[dy], 0, 0, 0);
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) ar[dy] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[dy][c + 2], w[dy].z, ar[dy], 0, 0, 0);
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) ar[dy] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[dy][c + 3], w[dy].w, ar[dy], 0, 0, 0);
+                }
+            }
+            f32x4 av;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = (ar[0][i] + ar[1][i]) + ar[2][i];
+            const int rb = wv * 64 + (lane & ~3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hval[(rb + i) * 4 + j] = fmaxf(av[i], 0.0f);   // hval is not read before the barriers below
+        }
+    } else if (tid < TB * CELLS) {
+        // other wave grids: one thread per board cell on the vector ALU, weights wave-uniform
         const int pos = tid % CELLS, y = pos / COLS, x = pos % COLS;
         const bool real = board0 + tid / CELLS < n_leaf;
         hv0 = P.val_b[0]; hv1 = P.val_b[1]; hv2 = P.val_b[2];
@@ -328,6 +401,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
             }
         }
     }
+    STAMP(52);
     __syncthreads();
     // policy-head activations over the (now dead) tower activations, value-head ones beside them
 #pragma unroll
@@ -337,12 +411,13 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
             const int row = wave * WROWS + mt * 32 + cd_row(v, lane);
             if (wc == 0) act[row * STRIDE + (lane & 31)] = fmaxf(accp[mt][0][v], 0.0f);
         }
-    if (tid < TB * CELLS) {
+    if (!VMFMA && tid < TB * CELLS) {
         hval[tid * 4 + 0] = fmaxf(hv0, 0.0f);
         hval[tid * 4 + 1] = fmaxf(hv1, 0.0f);
         hval[tid * 4 + 2] = fmaxf(hv2, 0.0f);
     }
     __syncthreads();
+    STAMP(53);
 
     // ---- Linear layers: Flatten is (c, y, x) order (resnet.py:60-61, :69-70) -------------------------
     float *logits = part + WG_ROWS * 8;            // [TB][AP]; value logit of board b at vlogit[b]
@@ -404,6 +479,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
         vlogit = part;
     }
     __syncthreads();
+    STAMP(54);
     // ---- masked softmax + tanh (ResNet.predict resnet.py:143-151; legal = the game's valid moves) --------
     if (tid < TB && board0 + tid < n_leaf) {
         const int j = board0 + tid;
@@ -421,6 +497,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
             out_p[(size_t)j * AP + a] = (a < A && G::legal(bmine, btheirs, a)) ? expf(lg[a] - mx) / den : 0.0f;
         out_v[j] = tanhf(vlogit ? vlogit[tid] : lg[7]);
     }
+    STAMP(55);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -486,6 +563,7 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
     n->o_pol_w = reserve((size_t)g.S * 64);
     n->o_pol_b = reserve(32);
     n->o_val_w = reserve((size_t)9 * g.Cp * 4);
+    n->o_val_w4 = reserve((size_t)9 * g.Cp * 4);
     n->o_val_b = reserve(32);
     n->o_fcp_w = reserve((size_t)POL_CH * g.cells * g.AP);
     n->o_fcp_b = reserve(g.AP);
@@ -558,6 +636,10 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
             for (int c2 = 0; c2 < g.C; ++c2)
                 for (int o = 0; o < VAL_CH; ++o)
                     host[n->o_val_w + ((size_t)tap * g.Cp + c2) * 4 + o] = w[((size_t)o * g.C + c2) * 9 + tap];
+        for (int tap = 0; tap < 9; ++tap)           // 4x4x1-MFMA layout: [tap][channel / 4][out][channel % 4]
+            for (int c2 = 0; c2 < g.C; ++c2)
+                for (int o = 0; o < VAL_CH; ++o)
+                    host[n->o_val_w4 + (((size_t)tap * g.Cp + (c2 & ~3)) + o) * 4 + (c2 & 3)] = w[((size_t)o * g.C + c2) * 9 + tap];
         for (int o = 0; o < VAL_CH; ++o) host[n->o_val_b + o] = b[o];
         const float *fw = take(p, (size_t)VAL_CH * g.cells), *fb = take(p, 1);
         for (int i = 0; i < VAL_CH * g.cells; ++i) host[n->o_fcv_w + i] = fw[i];
@@ -568,6 +650,49 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
     if (hipStreamSynchronize(s) != hipSuccess) return -4;
     if (n->f16) return resnet16_load(n->f16, blob, n_floats, s);
     return 0;
+}
+
+// AZSP_RESNET_TRACE (diagnostic): run the launch with per-workgroup phase timestamps, wait for it and print the
+// mean duration of every phase over the workgroups that ran (microseconds; 100 MHz clock) to stderr.
+template <class Launch>
+static void trace_forward(const NetParams &P, int grid, Launch launch, hipStream_t s) {
+    NetParams Q = P;
+    unsigned long long *d = nullptr;
+    const size_t n = (size_t)grid * 64;
+    if (hipMalloc((void **)&d, n * 8) != hipSuccess) { launch(P); return; }
+    (void)hipMemsetAsync(d, 0, n * 8, s);
+    Q.dbg = d;
+    launch(Q);
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h(n);
+    (void)hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    static int calls = 0;
+    if (++calls > 3) return;
+    double sum[64] = {};
+    unsigned long long t_min = ~0ull, t_max = 0;
+    int ran = 0;
+    for (int w = 0; w < grid; ++w) {
+        const unsigned long long *t = &h[(size_t)w * 64];
+        if (!t[55]) continue;
+        ++ran;
+        t_min = t[0] < t_min ? t[0] : t_min;
+        t_max = t[55] > t_max ? t[55] : t_max;
+        unsigned long long prev = t[0];
+        for (int k = 1; k < 56; ++k) if (t[k]) { sum[k] += (double)(t[k] - prev); prev = t[k]; }
+    }
+    if (!ran) return;
+    fprintf(stderr, "[azsp trace] %d workgroups, span %.1f us; mean phase durations (us):", ran, (t_max - t_min) * 0.01);
+    for (int k = 1; k < 56; ++k) if (sum[k] > 0) fprintf(stderr, " %d:%.2f", k, sum[k] / ran * 0.01);
+    // in-kernel clock over the residual tower: core-clock ticks / 100 MHz ticks (median would be better; mean is fine here)
+    double ghz = 0;
+    int cnt = 0;
+    for (int w = 0; w < grid; ++w) {
+        const unsigned long long *t = &h[(size_t)w * 64];
+        if (t[55] && t[58] > t[2]) { ghz += (double)(t[57] - t[56]) / (double)(t[58] - t[2]) * 0.1; ++cnt; }
+    }
+    if (cnt) fprintf(stderr, " | tower clock %.3f GHz", ghz / cnt);
+    fprintf(stderr, "\n");
 }
 
 template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4>
@@ -587,6 +712,16 @@ static void launch_forward(const NetParams &P, const u64 *mine, const u64 *their
         attr_set[dev] = true;
     }
     const int grid = (max_leaves + TB - 1) / TB;
+    if constexpr (std::is_same<G, Connect4>::value && NT == 2 && CW == 1) {     // traced instantiations: the 64-channel Connect-4 kernels
+        static const bool trace = getenv("AZSP_RESNET_TRACE") != nullptr;
+        if (trace) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT, MT, PF, CW, RW, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            trace_forward(P, grid, [&](const NetParams &Q) {
+                hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW, true>), dim3(grid), dim3(64 * RW * CW), lds, s, Q, mine, theirs, leaf_slot, n_leaf, out_p, out_v); }, s);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW>), dim3(grid), dim3(64 * RW * CW), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
 }
 
@@ -598,12 +733,13 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
     P.stem_w = d + n->o_stem_w; P.stem_b = d + n->o_stem_b;
     P.conv_w = d + n->o_conv_w; P.conv_b = d + n->o_conv_b;
     P.pol_w = d + n->o_pol_w; P.pol_b = d + n->o_pol_b;
-    P.val_w = d + n->o_val_w; P.val_b = d + n->o_val_b;
+    P.val_w = d + n->o_val_w; P.val_w4 = d + n->o_val_w4; P.val_b = d + n->o_val_b;
     P.fcp_w = d + n->o_fcp_w; P.fcp_b = d + n->o_fcp_b;
     P.fcv_w = d + n->o_fcv_w; P.fcv_b = d + n->o_fcv_b;
     P.conv_w_stride = (int)n->conv_w_stride;
     P.conv_b_stride = (int)n->conv_b_stride;
     P.blocks = n->g.blocks;
+    P.dbg = nullptr;
     if (game == 2) {       // Gomoku 9x9: 3 boards (243 rows) per workgroup up to 64 channels, 1 board (81 of 128 rows) above
 #define FWG(NTV, MTV, PFV) launch_forward<Gomoku9, NTV, MTV, PFV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
         // wide nets: one board (81 rows -> 3 row tiles) per workgroup, one wave per 32-channel column tile

@@ -1,0 +1,53 @@
+"""Stand-alone timing of the fused inference kernel: `azsp_predict` on B random mid-game boards, repeated;
+per-launch duration from the engine's HIP events (AZSP_FLAG_TIMING).  Usage (GPU box):
+    python tools/infer_bench.py --boards 3072 1536 6144 --reps 20 [--blocks 4 --channels 64] [--f16]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "alphazero-implementation_amd"))
+
+from azsp.engine import Engine            # noqa: E402
+from azsp.weights import resnet_blob      # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--boards", type=int, nargs="+", default=[3072])
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--blocks", type=int, default=4)
+    ap.add_argument("--channels", type=int, default=64)
+    ap.add_argument("--f16", action="store_true")
+    a = ap.parse_args()
+    import torch
+    from azsp.model import ResNet
+    torch.manual_seed(0)
+    blob = resnet_blob(ResNet((6, 7), 7, a.blocks, a.channels))[0]
+    rng = np.random.RandomState(0)
+    for B in a.boards:
+        boards = np.zeros((B, 6, 7), np.int8)
+        for b in boards:                       # random legal-looking fillings (gravity respected)
+            for c in range(7):
+                h = rng.randint(0, 6)
+                b[6 - h:, c] = rng.choice([-1, 1], size=h)
+        with Engine("connect4", B, 1, res_blocks=a.blocks, channels=a.channels, timing=True, f16_split=a.f16) as e:
+            e.load_resnet(blob)
+            e.predict(boards)
+            e.reset_stats()
+            for _ in range(a.reps):
+                e.predict(boards)
+            st = e.stats()
+        ms = st["infer_ms"] / st["infer_launches"]
+        flops = 25254012.0 if (a.blocks, a.channels) == (4, 64) else None
+        line = {"boards": B, "launch_ms": round(ms, 4), "boards_per_s": round(B / ms * 1e3)}
+        if flops:
+            line["tflops"] = round(B * flops / ms / 1e9, 1)
+            line["frac_fp32_peak"] = round(B * flops / ms / 1e9 / 157.3, 3)
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
