@@ -51,12 +51,14 @@ struct ResNetDev {
     size_t conv_w_stride, conv_b_stride;
     double flops_per_board = 0;
     ResNet16Dev *f16 = nullptr;   // split-fp16 variant (AZSP_FLAG_F16_SPLIT)
+    int32_t *d_perm = nullptr;    // row order of the tap-skipping Connect-4 kernels
 };
 
 struct NetParams {
     const float *stem_w, *stem_b, *conv_w, *conv_b, *pol_w, *pol_b, *val_w, *val_w4, *val_b, *fcp_w, *fcp_b, *fcv_w, *fcv_b;
     int conv_w_stride, conv_b_stride, blocks;
     unsigned long long *dbg;      // diagnostic phase timestamps (AZSP_RESNET_TRACE), else nullptr
+    const int32_t *perm;          // [256] GEMM row -> board-cell row of the tap-skipping row order (see build_row_order)
 };
 // phase timestamp of wave 0 of each workgroup, 100 MHz constant clock; compiled only into the TR = true
 // diagnostic instantiation (AZSP_RESNET_TRACE), the product kernels carry no stamp code
@@ -103,10 +105,50 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[MT][NTW], const float *
     }
 }
 
-template <class G, int MT, int NTW, int TAPS, int S, int PF, int WST = NTW>
+// One tap of a convolution for the row tiles selected by MASK (bit mt set = row tile mt takes part).
+template <int MT, int NTW, int S, int WST, int MASK>
+__device__ __forceinline__ void tap_mfma(f32x16 (&acc)[MT][NTW], const float *const (&arow)[MT], const float *wt) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        float w[NTW];
+        load_w<NTW>(wt + (size_t)s * 64 * WST, w);
+        float a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) if ((MASK >> mt) & 1) a[mt] = arow[mt][2 * s];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            if ((MASK >> mt) & 1) {
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], w[nt], acc[mt][nt], 0, 0, 0);
+            }
+    }
+}
+
+// `need[mt]` (wave-uniform): taps for which at least one row of row tile mt has an on-board input.  The other
+// taps multiply an all-zero A tile -- adding exactly 0 -- and are skipped (SK kernels order their rows so that
+// whole row tiles share their off-board taps; everywhere else every tap is needed by some row).
+template <class G, int MT, int NTW, int TAPS, int S, int PF, int WST = NTW, bool SK = false>
 __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *__restrict__ wl, const float *act,
                                           const int (&ridx)[MT], const uint32_t (&vmask)[MT], int stride, int zero_idx,
-                                          int lane) {
+                                          int lane, const uint32_t (&need)[MT]) {
+    if constexpr (PF == 0 && SK && MT == 2) {
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int t9 = (TAPS == 9) ? tap : 4;
+            const bool n0 = (need[0] >> t9) & 1u, n1 = (need[1] >> t9) & 1u;
+            if (!(n0 || n1)) continue;
+            const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+            const float *arow[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                arow[mt] = act + (((vmask[mt] >> t9) & 1u) ? ridx[mt] + (dy * G::COLS + dx) * stride : zero_idx);
+            const float *wt = wl + ((size_t)tap * S * 64 + lane) * WST;
+            if (n0 && n1) tap_mfma<MT, NTW, S, WST, 3>(acc, arow, wt);
+            else if (n0) tap_mfma<MT, NTW, S, WST, 1>(acc, arow, wt);
+            else tap_mfma<MT, NTW, S, WST, 2>(acc, arow, wt);
+        }
+        return;
+    }
     if constexpr (PF == 0) {
         // compiler-scheduled form: one load + MT LDS reads + MT*NTW MFMAs per k-step, fully unrolled per tap
         for (int tap = 0; tap < TAPS; ++tap) {
@@ -178,11 +220,14 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     constexpr int NTW = NT / CW;                   // column tiles per wave: CW waves share a row group
     static_assert(NT % CW == 0, "column tiles must divide over the column waves");
     constexpr int ZERO_IDX = WG_ROWS * STRIDE;
+    // tap skipping: 6 Connect-4 boards per workgroup in the row order of build_row_order()
+    constexpr bool SK = std::is_same<G, Connect4>::value && MT == 2 && RW == 4 && CW == 1 && PF == 0;
     extern __shared__ float smem[];
     float *act = smem;                             // [WG_ROWS + 1][STRIDE]
     constexpr int AP = G::AP;                      // actions padded to a multiple of 8
     float *part = smem + (WG_ROWS + 1) * STRIDE;   // [WG_ROWS][8] FC partial sums, then [TB][AP] logits
     float *hval = part + WG_ROWS * 8 + TB * AP;    // [WG_ROWS][4] value-head activations
+    int *s_perm = reinterpret_cast<int *>(hval + WG_ROWS * 4);   // [WG_ROWS] GEMM row -> board-cell row (SK only)
 
     const int n_leaf = *n_leaf_p;
     const int board0 = blockIdx.x * TB;
@@ -193,6 +238,12 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
 
     STAMP(0);
     for (int i = tid; i < STRIDE; i += NTHREADS) act[ZERO_IDX + i] = 0.0f;
+    if constexpr (SK) {
+        for (int i = tid; i < WG_ROWS; i += NTHREADS) s_perm[i] = P.perm[i];
+        __syncthreads();
+    }
+    // LDS row of GEMM row g (activations are stored by board cell; GEMM rows may be permuted)
+    auto lds_row = [&](int g) -> int { if constexpr (SK) return s_perm[g]; else return g; };
 
     // ---- per-lane row geometry -------------------------------------------------------------------
     int ridx[MT];
@@ -201,7 +252,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     int ry[MT], rx[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int r = wave * WROWS + mt * 32 + (lane & 31);
+        const int r = lds_row(wave * WROWS + mt * 32 + (lane & 31));
         const int b = r / CELLS, pos = r % CELLS;
         const int y = pos / COLS, x = pos % COLS;
         const bool real = r < TB * CELLS && board0 + b < n_leaf;
@@ -222,6 +273,14 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
             bm[mt] = board_load<G::W>(mine, slot);
             bt[mt] = board_load<G::W>(theirs, slot);
         }
+    }
+
+    uint32_t need[MT];            // wave-uniform: taps some row of the tile needs
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        uint32_t nd = 0;
+        for (int t = 0; t < 9; ++t) if (__ballot((vmask[mt] >> t) & 1u)) nd |= 1u << t;
+        need[mt] = nd;
     }
 
     f32x16 acc[MT][NTW], xres[MT][NTW];
@@ -270,7 +329,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
                 for (int v = 0; v < 16; ++v) {
                     const float o = fmaxf(acc[mt][nt][v], 0.0f);
                     xres[mt][nt][v] = o;
-                    act[(wave * WROWS + mt * 32 + cd_row(v, lane)) * STRIDE + col0 + nt * 32 + (lane & 31)] = o;
+                    act[lds_row(wave * WROWS + mt * 32 + cd_row(v, lane)) * STRIDE + col0 + nt * 32 + (lane & 31)] = o;
                 }
     }
     __syncthreads();
@@ -290,7 +349,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[mt][nt][v] = second ? xres[mt][nt][v] + bias : bias;   // x += residual
         }
-        conv_mfma<G, MT, NTW, 9, S, PF, NT>(acc, wl + wc * NTW, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
+        conv_mfma<G, MT, NTW, 9, S, PF, NT, SK>(acc, wl + wc * NTW, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane, need);
         if (layer < 16) STAMP(3 + 3 * layer);
         __syncthreads();                               // every wave is done reading the layer input
         if (layer < 16) STAMP(4 + 3 * layer);
@@ -302,7 +361,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
                 for (int v = 0; v < 16; ++v) {
                     const float o = fmaxf(acc[mt][nt][v], 0.0f);
                     if (second) xres[mt][nt][v] = o;
-                    act[(wave * WROWS + mt * 32 + cd_row(v, lane)) * STRIDE + col0 + nt * 32 + (lane & 31)] = o;
+                    act[lds_row(wave * WROWS + mt * 32 + cd_row(v, lane)) * STRIDE + col0 + nt * 32 + (lane & 31)] = o;
                 }
         __syncthreads();
         if (layer < 16) STAMP(5 + 3 * layer);
@@ -324,7 +383,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
             for (int v = 0; v < 16; ++v) accp[mt][0][v] = bp;
     }
     if (wc == 0)      // one 32-channel tile: the first column wave of each row group computes it
-        conv_mfma<G, MT, 1, 1, S, PF>(accp, P.pol_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane);
+        conv_mfma<G, MT, 1, 1, S, PF, 1, SK>(accp, P.pol_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane, need);
     STAMP(51);
     // The value conv has 3 output channels.  As a 32-wide MFMA tile it would cost +5.8 % MFMA time for 0.6 % of the
     // FLOPs; on the vector ALU it took 16 us of a 370 us workgroup (scalar weight loads and LDS reads sharing one
@@ -408,7 +467,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int row = wave * WROWS + mt * 32 + cd_row(v, lane);
+            const int row = lds_row(wave * WROWS + mt * 32 + cd_row(v, lane));
             if (wc == 0) act[row * STRIDE + (lane & 31)] = fmaxf(accp[mt][0][v], 0.0f);
         }
     if (!VMFMA && tid < TB * CELLS) {
@@ -546,6 +605,41 @@ static void permute_conv(const std::vector<float> &w, int oc, int ic, int k, int
                 }
 }
 
+// Row order of the tap-skipping kernels (6 Connect-4 boards = 252 cells + 4 padding rows in 8 row tiles of 32).
+// A 3x3 tap that falls off the board multiplies zeros; 74 of the 378 (cell, tap) pairs of a 6x7 board do.  A
+// 32-row MFMA tile can only drop a tap that ALL its rows lack, so the cells are grouped by which taps they lack:
+//   tile 0 of wave 0: 32 cells of the left column   (lack dx = -1: 3 taps)
+//   tile 0 of wave 1: 32 cells of the right column  (lack dx = +1)
+//   tile 0 of wave 2: the 30 inner cells of the top rows + 2 top-left corners     (lack dy = -1)
+//   tile 0 of wave 3: the 30 inner cells of the bottom rows + 2 bottom-left corners (lack dy = +1)
+//   tile 1 of every wave: interior cells, the 4 right-column cells left over and the 4 padding rows (all 9 taps)
+// Every wave then issues 15 instead of 18 tile-taps per layer (-16.7 % MFMAs), identically for all waves, and the
+// skipped products are exact zeros, so results do not change by a bit.
+static void build_row_order(int32_t *perm) {
+    constexpr int R = Connect4::ROWS, C = Connect4::COLS, CE = Connect4::CELLS, TBB = 6;
+    std::vector<int> left, right, top, bottom, interior, rest;
+    for (int b = 0; b < TBB; ++b)
+        for (int y = 0; y < R; ++y)
+            for (int x = 0; x < C; ++x) {
+                const int r = b * CE + y * C + x;
+                const bool corner_l = x == 0 && (y == 0 || y == R - 1) && b < 2;    // 2 top-left + 2 bottom-left corners
+                if (x == 0 && !corner_l) left.push_back(r);
+                else if (x == 0) (y == 0 ? top : bottom).push_back(r);
+                else if (x == C - 1) right.push_back(r);
+                else if (y == 0) top.push_back(r);
+                else if (y == R - 1) bottom.push_back(r);
+                else interior.push_back(r);
+            }
+    while (right.size() > 32) { rest.push_back(right.back()); right.pop_back(); }
+    for (int r = TBB * CE; r < 256; ++r) rest.push_back(r);
+    interior.insert(interior.end(), rest.begin(), rest.end());      // 120 + 4 + 4 = 128
+    const std::vector<int> *special[4] = {&left, &right, &top, &bottom};
+    for (int w = 0; w < 4; ++w) {
+        for (int i = 0; i < 32; ++i) perm[w * 64 + i] = (*special[w])[i];
+        for (int i = 0; i < 32; ++i) perm[w * 64 + 32 + i] = interior[w * 32 + i];
+    }
+}
+
 ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
     NetGeom g;
     if (!geom_for(game, blocks, channels, g)) return nullptr;
@@ -572,6 +666,12 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
     off += 8 * 64 * 4;                      // slack for the one-block weight prefetch past the last array
     n->blob_floats = off;
     if (hipMalloc((void **)&n->d_blob, off * sizeof(float)) != hipSuccess) { delete n; return nullptr; }
+    if (game == 0) {
+        int32_t perm[256];
+        build_row_order(perm);
+        if (hipMalloc((void **)&n->d_perm, sizeof perm) != hipSuccess ||
+            hipMemcpy(n->d_perm, perm, sizeof perm, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(n->d_blob); delete n; return nullptr; }
+    }
     const double C = g.C, cells = g.cells;
     n->flops_per_board = 2.0 * cells * (3 * 9 * C + 2.0 * blocks * C * C * 9 + C * POL_CH + C * 9 * VAL_CH) +
                          2.0 * (POL_CH * cells * g.A + VAL_CH * cells);
@@ -585,6 +685,7 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
 void resnet_destroy(ResNetDev *n) {
     if (!n) return;
     if (n->d_blob) (void)hipFree(n->d_blob);
+    if (n->d_perm) (void)hipFree(n->d_perm);
     if (n->f16) resnet16_destroy(n->f16);
     delete n;
 }
@@ -702,7 +803,7 @@ static void launch_forward(const NetParams &P, const u64 *mine, const u64 *their
     constexpr int TB = WG_ROWS / G::CELLS;
     static_assert(TB >= 1 && TB * G::CELLS <= 64 * RW * CW, "one thread per board cell in the head phases");
     constexpr int STRIDE = 32 * NT + 1;
-    const size_t lds = ((size_t)(WG_ROWS + 1) * STRIDE + WG_ROWS * 8 + TB * G::AP + WG_ROWS * 4) * sizeof(float);
+    const size_t lds = ((size_t)(WG_ROWS + 1) * STRIDE + WG_ROWS * 8 + TB * G::AP + WG_ROWS * 4 + WG_ROWS) * sizeof(float);
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -740,6 +841,7 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
     P.conv_b_stride = (int)n->conv_b_stride;
     P.blocks = n->g.blocks;
     P.dbg = nullptr;
+    P.perm = n->d_perm;
     if (game == 2) {       // Gomoku 9x9: 3 boards (243 rows) per workgroup up to 64 channels, 1 board (81 of 128 rows) above
 #define FWG(NTV, MTV, PFV) launch_forward<Gomoku9, NTV, MTV, PFV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
         // wide nets: one board (81 rows -> 3 row tiles) per workgroup, one wave per 32-channel column tile
