@@ -41,6 +41,7 @@ struct Net16Params {
     const float *conv_up, *conv_inv;   // per conv layer: 2^(ACT_SHIFT + k_l) and its inverse
     float stem_inv, pol_inv, val_inv;
     int conv_w_stride /* in h8 */, conv_b_stride, blocks;
+    const int32_t *perm;               // [256] GEMM row -> board-cell row for this wave grid (tap skipping)
 };
 
 struct ResNet16Dev {
@@ -51,6 +52,7 @@ struct ResNet16Dev {
     size_t o_stem_b, o_conv_b, o_pol_b, o_val_b, o_fcp_w, o_fcp_b, o_fcv_w, o_fcv_b, o_up, o_inv;   // float arrays
     size_t conv_w_stride = 0, conv_b_stride = 0;
     float stem_inv = 1, pol_inv = 1, val_inv = 1;
+    int32_t *d_perm = nullptr;          // [4][256]: row orders for WR = 1, 2, 4, 8
 };
 
 __device__ __forceinline__ int cd_row16(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
@@ -114,6 +116,60 @@ __device__ __forceinline__ void conv16(f32x16 (&acc)[NTILE], const h8 *__restric
     }
 }
 
+// The same convolution with tap skipping: `need[i]` (wave-uniform) = taps for which some row of tile i has an
+// on-board input; the others would add exact zeros.  The kernel orders its rows (perm) so that whole row tiles
+// lack the same taps -- see build_row_order16.  Loop order tap -> (weights of the tap in registers) -> tile -> slab.
+template <class G, int NTILE, int TAPS, int SL, int CT>
+__device__ __forceinline__ void conv16s(f32x16 (&acc)[NTILE], const h8 *__restrict__ w, const unsigned char *plane_hi,
+                                        int plane_bytes, const int (&abyte)[NTILE], const uint32_t (&vmask)[NTILE],
+                                        const uint32_t (&need)[NTILE], int row_bytes, int zero_byte, int lane) {
+    // the weights of a tap live in registers; the next tap's are requested while this tap's MFMAs run
+    h8 bh[SL], bl[SL], nh[SL], nl[SL];
+    auto load_b = [&](int tap, h8 (&h)[SL], h8 (&l)[SL]) {
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) {
+            const h8 *wp = w + ((size_t)(tap * SL + sl) * CT) * 2 * 64 + lane;
+            h[sl] = wp[0];
+            l[sl] = wp[64];
+        }
+    };
+    constexpr bool DB = SL <= 4;            // double-buffer only while the registers last (<= 64 channels)
+    if constexpr (DB) load_b(0, nh, nl);
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const int t9 = (TAPS == 9) ? tap : 4;
+        if constexpr (DB) {
+#pragma unroll
+            for (int sl = 0; sl < SL; ++sl) { bh[sl] = nh[sl]; bl[sl] = nl[sl]; }
+            if (tap + 1 < TAPS) load_b(tap + 1, nh, nl);
+        } else {
+            load_b(tap, bh, bl);
+        }
+        uint32_t any = 0;
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i) any |= (need[i] >> t9) & 1u;
+        if (!any) continue;
+        const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+        const unsigned char *ar[NTILE];
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i)
+            ar[i] = plane_hi + (((vmask[i] >> t9) & 1u) ? abyte[i] + (dy * G::COLS + dx) * row_bytes : zero_byte);
+        // (taking the tiles in pairs so that neighbouring MFMAs write different accumulators was measured: slower,
+        //  0.156 vs 0.146 ms per 1536-board launch -- the extra live fragments cost more than the dependences)
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i) {
+            if (!((need[i] >> t9) & 1u)) continue;
+#pragma unroll
+            for (int sl = 0; sl < SL; ++sl) {
+                const h8 ah = *reinterpret_cast<const h8 *>(ar[i] + sl * 32);
+                const h8 al = *reinterpret_cast<const h8 *>(ar[i] + sl * 32 + plane_bytes);
+                acc[i] = mfma16(ah, bh[sl], acc[i]);
+                acc[i] = mfma16(ah, bl[sl], acc[i]);
+                acc[i] = mfma16(al, bh[sl], acc[i]);
+            }
+        }
+    }
+}
+
 template <class G, int CT, int WR, int ABL = 0>
 __global__ __launch_bounds__(64 * WR * CT, 2)
 void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
@@ -131,6 +187,9 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     _Float16 *act_lo = reinterpret_cast<_Float16 *>(smem16 + PLANE_BYTES);
     float *hb = reinterpret_cast<float *>(smem16);               // after the tower: [256][HB_STRIDE] head activations
     float *part = hb + F16_ROWS * HB_STRIDE;                     // [256][8], then [TB][8] logits
+    constexpr int HEAD_BYTES = (F16_ROWS * HB_STRIDE + F16_ROWS * 8 + TB * 8) * 4;
+    constexpr int PERM_OFF = 2 * PLANE_BYTES > HEAD_BYTES ? 2 * PLANE_BYTES : HEAD_BYTES;     // behind both uses of the buffer
+    int *s_perm = reinterpret_cast<int *>(smem16 + PERM_OFF);    // [256] GEMM row -> board-cell row
 
     const int n_leaf = *n_leaf_p;
     const int board0 = blockIdx.x * TB;
@@ -139,8 +198,11 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     const int wr = wave / CT, wc = wave % CT;
 
     for (int i = tid; i < RS; i += NTHREADS) { act_hi[F16_ROWS * RS + i] = (_Float16)0; act_lo[F16_ROWS * RS + i] = (_Float16)0; }
+    for (int i = tid; i < F16_ROWS; i += NTHREADS) s_perm[i] = P.perm[i];
+    __syncthreads();
 
-    auto row_geom = [&](int r, uint32_t &vm, int &ab) {
+    auto row_geom = [&](int g, uint32_t &vm, int &ab) {     // g = GEMM row
+        const int r = s_perm[g];
         const int b = r / CELLS, pos = r % CELLS, y = pos / COLS, x = pos % COLS;
         const bool real = r < TB * CELLS && board0 + b < n_leaf;
         uint32_t m = 0;
@@ -152,10 +214,18 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         vm = m;
         ab = r * ROW_BYTES + half * 16;
     };
+    auto need_of = [&](uint32_t vm) -> uint32_t {            // wave-uniform OR of the rows' tap masks
+        uint32_t nd = 0;
+        for (int t = 0; t < 9; ++t) if (__ballot((vm >> t) & 1u)) nd |= 1u << t;
+        return nd;
+    };
     int abyte[MT];
-    uint32_t vmask[MT];
+    uint32_t vmask[MT], need[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) row_geom(wr * (MT * 32) + mt * 32 + r32, vmask[mt], abyte[mt]);
+    for (int mt = 0; mt < MT; ++mt) {
+        row_geom(wr * (MT * 32) + mt * 32 + r32, vmask[mt], abyte[mt]);
+        need[mt] = need_of(vmask[mt]);
+    }
 
     f32x16 acc[MT], xres[MT];
     const int col = wc * 32 + r32;                                // output channel of this lane
@@ -171,7 +241,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
                 const float as = fminf(o * ACT_SCALE, 65504.0f);
                 const _Float16 hi = (_Float16)as;
                 const _Float16 lo = (_Float16)(as - (float)hi);
-                const int idx = (wr * (MT * 32) + mt * 32 + cd_row16(v, lane)) * RS + col;
+                const int idx = s_perm[wr * (MT * 32) + mt * 32 + cd_row16(v, lane)] * RS + col;
                 if ((ABL & 4) && v > 0) continue;
                 act_hi[idx] = hi;
                 act_lo[idx] = lo;
@@ -191,7 +261,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
             const h8 bh = wp[0], bl = wp[64];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int r = wr * (MT * 32) + mt * 32 + r32;
+                const int r = s_perm[wr * (MT * 32) + mt * 32 + r32];
                 const int b = r / CELLS, pos = r % CELLS, y = pos / COLS, x = pos % COLS;
                 u64 bm = 0, bt = 0;
                 if (r < TB * CELLS && board0 + b < n_leaf) { const int slot = leaf_slot[board0 + b]; bm = mine[slot]; bt = theirs[slot]; }
@@ -225,8 +295,12 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[mt][v] = second ? fmaf(xres[mt][v], up, bias) : bias;
-        conv16<G, MT, 9, SL, CT, ABL>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
-                                 abyte, vmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+        if constexpr (ABL == 0)
+            conv16s<G, MT, 9, SL, CT>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
+                                      abyte, vmask, need, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+        else
+            conv16<G, MT, 9, SL, CT, ABL>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
+                                          abyte, vmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
         __syncthreads();
         store_act(acc, P.conv_inv[layer], second);
         __syncthreads();
@@ -236,7 +310,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     //      group are dealt round-robin to its CT waves -----------------------------------------------------
     f32x16 accp[PT], accv[PT];
     int hbyte[PT], hrow0[PT];
-    uint32_t hmask[PT];
+    uint32_t hmask[PT], hneed[PT];
     {
         const float bp = P.pol_b[r32], bv = P.val_b[r32];
 #pragma unroll
@@ -245,19 +319,20 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
             hrow0[i] = mt < MT ? wr * (MT * 32) + mt * 32 : -1;
             row_geom(hrow0[i] < 0 ? F16_ROWS - 1 : hrow0[i] + r32, hmask[i], hbyte[i]);
             if (hrow0[i] < 0) hmask[i] = 0;
+            hneed[i] = need_of(hmask[i]);
 #pragma unroll
             for (int v = 0; v < 16; ++v) { accp[i][v] = bp; accv[i][v] = bv; }
         }
     }
-    conv16<G, PT, 1, SL, 1>(accp, P.pol_w, plane_hi, PLANE_BYTES, hbyte, hmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
-    conv16<G, PT, 9, SL, 1>(accv, P.val_w, plane_hi, PLANE_BYTES, hbyte, hmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+    conv16s<G, PT, 1, SL, 1>(accp, P.pol_w, plane_hi, PLANE_BYTES, hbyte, hmask, hneed, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+    conv16s<G, PT, 9, SL, 1>(accv, P.val_w, plane_hi, PLANE_BYTES, hbyte, hmask, hneed, ROW_BYTES, ZERO_BYTE + half * 16, lane);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PT; ++i)
         if (hrow0[i] >= 0) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int row = hrow0[i] + cd_row16(v, lane);
+                const int row = s_perm[hrow0[i] + cd_row16(v, lane)];     // s_perm lies beyond the head buffers
                 hb[row * HB_STRIDE + r32] = fmaxf(accp[i][v] * P.pol_inv, 0.0f);
                 if (r32 < VAL_CH) hb[row * HB_STRIDE + POL_CH + r32] = fmaxf(accv[i][v] * P.val_inv, 0.0f);
             }
@@ -341,6 +416,38 @@ static void permute_split(const std::vector<float> &w, int oc, int ic, int taps,
                     }
 }
 
+// Row orders for tap skipping (see build_row_order in azsp_resnet.hip for the idea): the 252 cells of 6 boards + 4
+// padding rows as 8 row tiles of 32 -- left column, right column, top rows, bottom rows (each lacking 3 of the 9 taps)
+// and 4 tiles of interior cells.  Row group wr of a WR x CT wave grid owns tiles [wr*MT, (wr+1)*MT): the special
+// tiles are dealt round-robin to the row groups so that every wave skips the same number of tile-taps.
+static void build_row_order16(int WR, int32_t *perm) {
+    constexpr int R = Connect4::ROWS, C = Connect4::COLS, CE = Connect4::CELLS, TBB = 6;
+    std::vector<int> cls[4], interior, rest;       // 0 left, 1 right, 2 top, 3 bottom
+    for (int b = 0; b < TBB; ++b)
+        for (int y = 0; y < R; ++y)
+            for (int x = 0; x < C; ++x) {
+                const int r = b * CE + y * C + x;
+                const bool corner_l = x == 0 && (y == 0 || y == R - 1) && b < 2;
+                if (x == 0 && !corner_l) cls[0].push_back(r);
+                else if (x == 0) cls[y == 0 ? 2 : 3].push_back(r);
+                else if (x == C - 1) cls[1].push_back(r);
+                else if (y == 0) cls[2].push_back(r);
+                else if (y == R - 1) cls[3].push_back(r);
+                else interior.push_back(r);
+            }
+    while (cls[1].size() > 32) { rest.push_back(cls[1].back()); cls[1].pop_back(); }
+    for (int r = TBB * CE; r < F16_ROWS; ++r) rest.push_back(r);
+    interior.insert(interior.end(), rest.begin(), rest.end());      // 128 rows
+    const int MT = 8 / WR;
+    int next_int = 0, g = 0;
+    for (int wr = 0; wr < WR; ++wr) {
+        int filled = 0;
+        for (int sp = 0; sp < 4; ++sp)
+            if (sp % WR == wr && filled < MT) { for (int i = 0; i < 32; ++i) perm[g++] = cls[sp][i]; ++filled; }
+        for (; filled < MT; ++filled) for (int i = 0; i < 32; ++i) perm[g++] = interior[next_int++];
+    }
+}
+
 ResNet16Dev *resnet16_create(int game, int blocks, int channels) {
     if (game != 0 || blocks < 0 || channels <= 0) return nullptr;
     const int CT = (channels + 31) / 32;
@@ -368,12 +475,21 @@ ResNet16Dev *resnet16_create(int game, int blocks, int channels) {
     n->o_inv = reserve((size_t)(2 * blocks + 1) * 4);
     n->bytes = off;
     if (hipMalloc((void **)&n->d_blob, off) != hipSuccess) { delete n; return nullptr; }
+    std::vector<int32_t> perm(4 * F16_ROWS);
+    for (int k = 0; k < 4; ++k) build_row_order16(1 << k, perm.data() + (size_t)k * F16_ROWS);
+    if (hipMalloc((void **)&n->d_perm, perm.size() * sizeof(int32_t)) != hipSuccess ||
+        hipMemcpy(n->d_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(n->d_blob);
+        delete n;
+        return nullptr;
+    }
     return n;
 }
 
 void resnet16_destroy(ResNet16Dev *n) {
     if (!n) return;
     if (n->d_blob) (void)hipFree(n->d_blob);
+    if (n->d_perm) (void)hipFree(n->d_perm);
     delete n;
 }
 
@@ -452,7 +568,7 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, c
     constexpr int WAVES = WR * CT, RS = 32 * CT + 8, TB = F16_ROWS / G::CELLS;
     constexpr size_t planes = (size_t)2 * (F16_ROWS + 1) * RS * 2;
     constexpr size_t heads = ((size_t)F16_ROWS * HB_STRIDE + F16_ROWS * 8 + TB * 8) * 4;
-    const size_t lds = planes > heads ? planes : heads;
+    const size_t lds = (planes > heads ? planes : heads) + F16_ROWS * sizeof(int32_t);   // + the row-order table
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -462,7 +578,9 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, c
         attr_set[dev] = true;
     }
     const int grid = (max_leaves + TB - 1) / TB;
-    hipLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR, ABL>), dim3(grid), dim3(64 * WAVES), lds, s, P, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
+    Net16Params Q = P;
+    Q.perm = P.perm + (size_t)(WR == 1 ? 0 : WR == 2 ? 1 : WR == 4 ? 2 : 3) * F16_ROWS;      // row order of this wave grid
+    hipLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR, ABL>), dim3(grid), dim3(64 * WAVES), lds, s, Q, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
 }
 
 void resnet16_forward(ResNet16Dev *n, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
@@ -477,6 +595,7 @@ void resnet16_forward(ResNet16Dev *n, const u64 *mine, const u64 *theirs, const 
     P.conv_up = F(n->o_up); P.conv_inv = F(n->o_inv);
     P.stem_inv = n->stem_inv; P.pol_inv = n->pol_inv; P.val_inv = n->val_inv;
     P.conv_w_stride = (int)n->conv_w_stride; P.conv_b_stride = (int)n->conv_b_stride; P.blocks = n->blocks;
+    P.perm = n->d_perm;
     // wave grid WR x CT over the 256-row x C tile (tuning knob AZSP_F16_WR; results do not depend on it)
     static const int wr_env = [] { const char *e = getenv("AZSP_F16_WR"); return e ? atoi(e) : 0; }();
 #define L16(CTV, WRV) launch16<CTV, WRV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
