@@ -208,7 +208,7 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
 __device__ __forceinline__ int cd_row(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
 
 template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4, bool TR = false>
-__global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 && NT <= 2 ? 3 : (RW * CW > 8 ? RW * CW / 4 : 2))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
+__global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 && NT <= 2 ? 3 : (RW * CW > 8 ? RW * CW / 4 : (RW * CW == 8 && MT == 2 && RW == 4 ? 1 : 2)))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
                                                          const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
                                                          float *__restrict__ out_p, float *__restrict__ out_v) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     static_assert(NT % CW == 0, "column tiles must divide over the column waves");
     constexpr int ZERO_IDX = WG_ROWS * STRIDE;
     // tap skipping: 6 Connect-4 boards per workgroup in the row order of build_row_order()
-    constexpr bool SK = std::is_same<G, Connect4>::value && MT == 2 && RW == 4 && CW == 1 && PF == 0;
+    constexpr bool SK = std::is_same<G, Connect4>::value && MT == 2 && RW == 4 && PF == 0;
     extern __shared__ float smem[];
     float *act = smem;                             // [WG_ROWS + 1][STRIDE]
     constexpr int AP = G::AP;                      // actions padded to a multiple of 8
@@ -879,7 +879,13 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
     // (splitting the four column tiles of a 128-channel net over four waves for small batches was measured:
     //  2.33 vs 1.90 ms per 100-board launch -- the single-workgroup latency is set by the weight stream, which
     //  gets four times more load instructions per MFMA, not by the MFMA chain)
-    else if (n->g.NT == 4) { if (pf == 0) FWD(4, 1, 0); else FWD(4, 1, 1); }
+    else if (n->g.NT == 4) {
+        // large batches: 6 boards per workgroup on 8 waves (4 row groups x 2 column groups), one workgroup per CU, so
+        // that the tap-skipping row order applies; small batches keep 3 boards per 4-wave workgroup
+        static const int wide6 = [] { const char *e = getenv("AZSP_RESNET_WIDE6"); return e ? atoi(e) : 1; }();
+        if (wide6 && !small) launch_forward<Connect4, 4, 2, 0, 2, 4>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+        else if (pf == 0) FWD(4, 1, 0); else FWD(4, 1, 1);
+    }
     // 192 / 256 channels: 3 boards (128 rows) per workgroup, 2 row groups x NT/2 column groups of waves
     else if (n->g.NT == 6) launch_forward<Connect4, 6, 2, 1, 3, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
     else launch_forward<Connect4, 8, 2, 1, 4, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
