@@ -853,17 +853,16 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
 #undef FWG
         return;
     }
-    // rows per workgroup: 2 row tiles per wave (6 boards / WG) by default; AZSP_RESNET_MT=1 selects
-    // 1 row tile per wave (3 boards / WG, more workgroups per CU) -- same results, tuning knob only
-    // small batches are latency-bound (one workgroup's serial MFMA chain): halve the rows per workgroup
+    // Variant selection (all variants give bitwise the same outputs; measured choices):
+    //   large batches  : 2 row tiles per wave = 6 boards per workgroup, rows in the tap-skipping order, weight stream
+    //                    scheduled by the compiler (PF = 0)
+    //   <= 768 boards  : latency-bound (one workgroup's serial chain): 1 row tile per wave = 3 boards per workgroup and
+    //                    the explicit double-buffered weight stream (PF = 1)
+    // AZSP_RESNET_MT / _PF / _CW / _WIDE6 override the choice for tuning.
     static const int mt_env = [] { const char *e = getenv("AZSP_RESNET_MT"); return e ? atoi(e) : 0; }();
     const int mt = mt_env ? mt_env : (max_leaves <= 768 ? 1 : 2);
     static const int pf = [] { const char *e = getenv("AZSP_RESNET_PF"); return e ? atoi(e) : -1; }();
 #define FWD(NTV, MTV, PFV) launch_forward<Connect4, NTV, MTV, PFV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
-    // PF: explicit register double-buffering of the weight stream (helps the wide nets at MT=1; the
-    // 64-channel MT=2 kernel is faster with the compiler's own schedule) -- measured, see DESIGN.md
-    // measured: large batches are fastest with 2 row tiles per wave and the compiler's own
-    // schedule; latency-bound small batches with 1 row tile per wave and the explicit weight double-buffer
     const bool small = max_leaves <= 768;
     if (n->g.NT == 1) { if (mt == 1) { if (pf == 0) FWD(1, 1, 0); else FWD(1, 1, 1); } else FWD(1, 2, 0); }
     else if (n->g.NT == 2) {
