@@ -17,6 +17,7 @@
 // in LDS as two fp16 planes [row][C+8] (row stride = odd number of 16-byte slots: conflict-free
 // ds_read_b128), residual in fp32 registers, single fp32 accumulator per tile.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -42,7 +43,10 @@ struct Net16Params {
     float stem_inv, pol_inv, val_inv;
     int conv_w_stride /* in h8 */, conv_b_stride, blocks;
     const int32_t *perm;               // [256] GEMM row -> board-cell row for this wave grid (tap skipping)
+    unsigned long long *dbg;           // phase timestamps of the ABL = 8 diagnostic instantiation, else nullptr
 };
+// phase timestamp (100 MHz clock) of wave 0 of each workgroup; compiled only into the ABL & 8 diagnostic build
+#define STAMP16(k) do { if constexpr ((ABL & 8) != 0) { if (tid == 0) P.dbg[(size_t)blockIdx.x * 64 + (k)] = wall_clock64(); } } while (0)
 
 struct ResNet16Dev {
     int CT = 0, C = 0, blocks = 0, cells = 0, A = 0;
@@ -196,6 +200,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     if (board0 >= n_leaf) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r32 = lane & 31;
     const int wr = wave / CT, wc = wave % CT;
+    STAMP16(0);
 
     for (int i = tid; i < RS; i += NTHREADS) { act_hi[F16_ROWS * RS + i] = (_Float16)0; act_lo[F16_ROWS * RS + i] = (_Float16)0; }
     for (int i = tid; i < F16_ROWS; i += NTHREADS) s_perm[i] = P.perm[i];
@@ -285,6 +290,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         store_act(acc, P.stem_inv, true);
     }
     __syncthreads();
+    STAMP16(2);
 
     // ---- residual blocks ---------------------------------------------------------------------------------
     for (int layer = 0; layer < 2 * P.blocks; ++layer) {
@@ -295,15 +301,18 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[mt][v] = second ? fmaf(xres[mt][v], up, bias) : bias;
-        if constexpr (ABL == 0)
+        if constexpr ((ABL & 7) == 0)
             conv16s<G, MT, 9, SL, CT>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
                                       abyte, vmask, need, ROW_BYTES, ZERO_BYTE + half * 16, lane);
         else
             conv16<G, MT, 9, SL, CT, ABL>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
                                           abyte, vmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+        if (layer < 16) STAMP16(3 + 3 * layer);
         __syncthreads();
+        if (layer < 16) STAMP16(4 + 3 * layer);
         store_act(acc, P.conv_inv[layer], second);
         __syncthreads();
+        if (layer < 16) STAMP16(5 + 3 * layer);
     }
 
     // ---- heads: policy 1x1 and value 3x3 convs, one 32-wide column tile each; the row tiles of a row
@@ -325,7 +334,9 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         }
     }
     conv16s<G, PT, 1, SL, 1>(accp, P.pol_w, plane_hi, PLANE_BYTES, hbyte, hmask, hneed, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+    STAMP16(51);
     conv16s<G, PT, 9, SL, 1>(accv, P.val_w, plane_hi, PLANE_BYTES, hbyte, hmask, hneed, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+    STAMP16(52);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PT; ++i)
@@ -338,6 +349,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
             }
         }
     __syncthreads();
+    STAMP16(53);
 
     // ---- Linear layers, masked softmax, tanh: identical to the fp32 kernel --------------------------------
     if (tid < TB * CELLS) {
@@ -383,6 +395,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         for (int a = 0; a < PSTRIDE; ++a) out_p[(size_t)j * PSTRIDE + a] = a < A ? ex[a < A ? a : 0] / den : 0.0f;
         out_v[j] = tanhf(logits[tid * 8 + 7]);
     }
+    STAMP16(55);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -596,12 +609,51 @@ void resnet16_forward(ResNet16Dev *n, const u64 *mine, const u64 *theirs, const 
     P.stem_inv = n->stem_inv; P.pol_inv = n->pol_inv; P.val_inv = n->val_inv;
     P.conv_w_stride = (int)n->conv_w_stride; P.conv_b_stride = (int)n->conv_b_stride; P.blocks = n->blocks;
     P.perm = n->d_perm;
+    P.dbg = nullptr;
     // wave grid WR x CT over the 256-row x C tile (tuning knob AZSP_F16_WR; results do not depend on it)
     static const int wr_env = [] { const char *e = getenv("AZSP_F16_WR"); return e ? atoi(e) : 0; }();
 #define L16(CTV, WRV) launch16<CTV, WRV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
     switch (n->CT) {
         case 1: if (wr_env == 8 || (!wr_env && max_leaves <= 768)) L16(1, 8); else L16(1, 4); break;
         case 2: {
+            static const bool trace = getenv("AZSP_RESNET_TRACE") != nullptr;
+            if (trace) {     // diagnostic instantiation with per-phase timestamps (prints like the fp32 kernel's trace)
+                constexpr int TBB = F16_ROWS / Connect4::CELLS;
+                const int grid = (max_leaves + TBB - 1) / TBB;
+                unsigned long long *dd = nullptr;
+                const size_t cnt = (size_t)grid * 64;
+                if (hipMalloc((void **)&dd, cnt * 8) == hipSuccess) {
+                    (void)hipMemsetAsync(dd, 0, cnt * 8, s);
+                    Net16Params Q = P;
+                    Q.dbg = dd;
+                    launch16<2, 2, 8>(Q, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+                    (void)hipStreamSynchronize(s);
+                    std::vector<unsigned long long> h(cnt);
+                    (void)hipMemcpy(h.data(), dd, cnt * 8, hipMemcpyDeviceToHost);
+                    (void)hipFree(dd);
+                    static int calls = 0;
+                    if (++calls <= 3) {
+                        double sum[64] = {};
+                        int ran = 0;
+                        unsigned long long t0 = ~0ull, t1 = 0;
+                        for (int w = 0; w < grid; ++w) {
+                            const unsigned long long *t = &h[(size_t)w * 64];
+                            if (!t[55]) continue;
+                            ++ran;
+                            t0 = t[0] < t0 ? t[0] : t0;
+                            t1 = t[55] > t1 ? t[55] : t1;
+                            unsigned long long prev = t[0];
+                            for (int k = 1; k < 56; ++k) if (t[k]) { sum[k] += (double)(t[k] - prev); prev = t[k]; }
+                        }
+                        if (ran) {
+                            fprintf(stderr, "[azsp trace f16x2] %d workgroups, span %.1f us; mean phase durations (us):", ran, (t1 - t0) * 0.01);
+                            for (int k = 1; k < 56; ++k) if (sum[k] > 0) fprintf(stderr, " %d:%.2f", k, sum[k] / ran * 0.01);
+                            fprintf(stderr, "\n");
+                        }
+                    }
+                    break;
+                }
+            }
             static const int abl = [] { const char *e = getenv("AZSP_F16_ABLATE"); return e ? atoi(e) : 0; }();
             if (abl) {   // timing-only diagnostic builds (wrong results): 1 = no weight streaming, 2 = no LDS fragment traffic, 4 = no activation stores
                 if (abl == 1) launch16<2, 2, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
