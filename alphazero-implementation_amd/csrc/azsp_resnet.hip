@@ -442,23 +442,34 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
             for (int i = 0; i < 4; ++i) hval[(rb + i) * 4 + j] = fmaxf(av[i], 0.0f);   // hval is not read before the barriers below
         }
     } else if (tid < TB * CELLS) {
-        // other wave grids: one thread per board cell on the vector ALU, weights wave-uniform
+        // other wave grids: one thread per board cell on the vector ALU, weights wave-uniform; the SAME three
+        // fma chains (one per kernel row, bias in the first, summed (r0 + r1) + r2) as the MFMA form, so that every
+        // variant of the kernel returns the same bits for a position
         const int pos = tid % CELLS, y = pos / COLS, x = pos % COLS;
         const bool real = board0 + tid / CELLS < n_leaf;
-        hv0 = P.val_b[0]; hv1 = P.val_b[1]; hv2 = P.val_b[2];
-        for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            const bool ok = real && yy >= 0 && yy < ROWS && xx >= 0 && xx < COLS;
-            const float *xr = act + (ok ? (tid + (t / 3 - 1) * COLS + (t % 3 - 1)) * STRIDE : ZERO_IDX);
-            const float *wv = P.val_w + (size_t)t * CP * 4;
-#pragma unroll 8
-            for (int c = 0; c < CP; ++c) {
-                const float a = xr[c];
-                hv0 = fmaf(a, wv[c * 4 + 0], hv0);
-                hv1 = fmaf(a, wv[c * 4 + 1], hv1);
-                hv2 = fmaf(a, wv[c * 4 + 2], hv2);
+        float hr[3][3] = {{P.val_b[0], P.val_b[1], P.val_b[2]}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+        for (int dx = 0; dx < 3; ++dx) {
+            const float *xr[3], *wv[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = y + dy - 1, xx = x + dx - 1;
+                const bool ok = real && yy >= 0 && yy < ROWS && xx >= 0 && xx < COLS;
+                xr[dy] = act + (ok ? (tid + (dy - 1) * COLS + (dx - 1)) * STRIDE : ZERO_IDX);
+                wv[dy] = P.val_w + (size_t)(dy * 3 + dx) * CP * 4;
             }
+#pragma unroll 4
+            for (int c = 0; c < CP; ++c)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const float a = xr[dy][c];
+                    hr[dy][0] = fmaf(a, wv[dy][c * 4 + 0], hr[dy][0]);
+                    hr[dy][1] = fmaf(a, wv[dy][c * 4 + 1], hr[dy][1]);
+                    hr[dy][2] = fmaf(a, wv[dy][c * 4 + 2], hr[dy][2]);
+                }
         }
+        hv0 = (hr[0][0] + hr[1][0]) + hr[2][0];
+        hv1 = (hr[0][1] + hr[1][1]) + hr[2][1];
+        hv2 = (hr[0][2] + hr[1][2]) + hr[2][2];
     }
     STAMP(52);
     __syncthreads();

@@ -238,6 +238,45 @@ def test_resnet_model_predict_uses_device_kernel(azsp, blocks, ch, f16, monkeypa
     assert not np.allclose(np.stack(p2), np.stack(p))
 
 
+@pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
+@pytest.mark.parametrize("blocks,ch", [(4, 64), (2, 128), (2, 32)])
+def test_resnet_every_batch_regime_returns_the_same_bits(azsp, blocks, ch, f16):
+    """The engine picks a kernel variant by batch size (<= 768 boards: 3 boards per workgroup; above: 6 boards per
+    workgroup with the rows in tap-skipping order, other wave grids).  A position's (P, V) must not depend on it:
+    the same boards through a small batch, a large batch and a large batch in another order are compared bitwise
+    (this is what makes the tap-skipping order and the MFMA value head testable: they are exact rearrangements)."""
+    import torch
+    from azsp.weights import resnet_blob
+    torch.manual_seed(ch + blocks)
+    net = azsp.ResNet((6, 7), 7, blocks, ch).eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    blob = resnet_blob(net)[0]
+    rules = oz.C4Rules()
+    rng = np.random.RandomState(7)
+    boards = np.stack(random_midgame_boards(rules, rng, 1500, 41))
+    with _engine(azsp, "connect4", 1500, 1, res_blocks=blocks, channels=ch, f16_split=f16) as e:
+        e.load_resnet(blob)
+        p_big, v_big = e.predict(boards)                      # one 1500-board launch: large-batch variant
+        perm = rng.permutation(1500)
+        p_perm, v_perm = e.predict(boards[perm])              # other tiles, other rows of the row order
+        p_odd, v_odd = e.predict(boards[:1003])               # a partly filled last workgroup
+    with _engine(azsp, "connect4", 100, 1, res_blocks=blocks, channels=ch, f16_split=f16) as e:
+        e.load_resnet(blob)
+        p_small, v_small = e.predict(boards)                  # 100-board launches: small-batch variant
+    assert np.array_equal(p_perm, p_big[perm]) and np.array_equal(v_perm, v_big[perm])
+    assert np.array_equal(p_odd, p_big[:1003]) and np.array_equal(v_odd, v_big[:1003])
+    assert np.array_equal(p_small, p_big) and np.array_equal(v_small, v_big)
+    with torch.no_grad():                                     # and all of it is the network (tolerance as elsewhere)
+        logits, vl = net.forward(net._states_to_tensor(list(boards[:64])))
+        mask = torch.tensor([rules.valid_moves(b) for b in boards[:64]])
+        pt = torch.softmax(logits.masked_fill(mask == 0, float("-inf")), dim=1).numpy()
+    assert np.max(np.abs(p_big[:64] - pt)) < 1e-5 and np.max(np.abs(v_big[:64] - torch.tanh(vl).numpy())) < 1e-5
+
+
 # ------------------------------------------------------------------------------------ full size
 def test_full_size_config2_properties(azsp):
     """BASELINE.json configs[1]: Connect-4, 64-ch/4-block ResNet, 100 sims, 4096 concurrent games.
