@@ -101,6 +101,13 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise AzspError(f"{LIB_PATH} is missing: build it with `python alphazero-implementation_amd/build.py` "
                         "(the self-play engine has no CPU fallback)")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.  If libazsp pulled in the system copy
+    # first, a later `import torch` would load a second runtime, which then finds no GPU ("No HIP GPUs are
+    # available").  Importing torch first makes libazsp bind to the copy that is already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)         # AttributeError if the symbol is not exported

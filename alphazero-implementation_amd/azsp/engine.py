@@ -190,18 +190,21 @@ class Engine:
         self._check(self.lib.azsp_play_commit(self._h, int(allow), C.byref(res)))
         return res
 
-    def fetch_episodes(self, first: int, n: int) -> dict[str, np.ndarray]:
-        cap = n * self.max_plies
-        out = {"ep_offset": np.zeros(n + 1, np.int64), "ep_slot": np.zeros(n, np.int32), "ep_ply": np.zeros(n, np.int32),
-               "states": np.empty((cap, self.cells), np.int8), "policies": np.empty((cap, self.n_actions), np.float64),
-               "values": np.empty(cap, np.int32)}
+    def fetch_episodes(self, first: int, n: int, arrays: bool = True) -> dict[str, np.ndarray]:
+        """Episodes [first, first+n) as SoA numpy buffers; `arrays=False` copies only the episode table."""
+        out = {"ep_offset": np.zeros(n + 1, np.int64), "ep_slot": np.zeros(n, np.int32), "ep_ply": np.zeros(n, np.int32)}
+        cap = n * self.max_plies if arrays else 0
+        if arrays:
+            out.update(states=np.empty((cap, self.cells), np.int8), policies=np.empty((cap, self.n_actions), np.float64),
+                       values=np.empty(cap, np.int32))
         self._check(self.lib.azsp_fetch_episodes(self._h, first, n, _ptr(out["ep_offset"], C.c_int64),
                                                  _ptr(out["ep_slot"], C.c_int32), _ptr(out["ep_ply"], C.c_int32),
-                                                 _ptr(out["states"], C.c_int8), _ptr(out["policies"], C.c_double),
-                                                 _ptr(out["values"], C.c_int32), cap))
+                                                 _ptr(out.get("states"), C.c_int8), _ptr(out.get("policies"), C.c_double),
+                                                 _ptr(out.get("values"), C.c_int32), cap))
         ns = int(out["ep_offset"][n])
         for k in ("states", "policies", "values"):
-            out[k] = out[k][:ns]
+            if k in out:
+                out[k] = out[k][:ns]
         return out
 
     def export_records_device(self, first: int, n: int, dev_ptr: int, cap_records: int) -> int:

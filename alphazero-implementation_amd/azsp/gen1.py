@@ -388,6 +388,49 @@ class EpisodeGenerator:
         return ep
 
 
+def generate_dataset(gen: EpisodeGenerator, initial_state=None, device=None):
+    """One generation of `gen` without materialising State / Episode objects: the three training tensors that
+    `Model.format_dataset` (models/base/model.py:76-82) builds for the reference's CNNModel
+    (`_states_to_tensor` models/games/connect4/cnn.py:77-98: planes [empty, side to move, opponent] in the grid's own
+    row order, row 0 = bottom; `_policies_to_tensor` models/games/connect4/model.py:45-51; values = the outcome
+    vector per player), written on the GPU by the engine's export kernel and re-oriented with torch ops:
+    TensorDataset(planes float32[S,3,6,7], policies float32[S,7], values float32[S,2])."""
+    import torch
+    from torch.utils.data import TensorDataset
+    if initial_state is None:
+        initial_state = gen.game_initial_state
+    n = gen.num_episodes
+    gen.search._anchor(initial_state)
+    eng = gen.search.engine_for(n, exact=True)
+    init_cells = canonical_cells(initial_state)
+    eng.set_initial_board(init_cells if init_cells.any() else None)
+    eng.reset()
+    eng.search()
+    while True:
+        rng_state = np.random.get_state()
+        res = eng.play(np.random.random_sample(n))
+        if res.uniforms_used < n:
+            np.random.set_state(rng_state)
+            np.random.random_sample(res.uniforms_used)
+        if res.finished:
+            break
+        eng.search()
+    gen.last_stats = eng.stats()
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    s = int(res.samples_total)
+    planes = torch.empty((s, 3, eng.rows, eng.cols), dtype=torch.float32, device=device)
+    pol = torch.empty((s, eng.n_actions), dtype=torch.float32, device=device)
+    z = torch.empty((s,), dtype=torch.float32, device=device)
+    got = eng.export_dataset_device(0, n, planes.data_ptr(), pol.data_ptr(), z.data_ptr(), s)
+    assert got == s
+    # the engine's z is the outcome for the sample's side to move; gen-1 stores the vector over absolute players
+    off = eng.fetch_episodes(0, n, arrays=False)["ep_offset"]
+    ply = np.concatenate([np.arange(off[e + 1] - off[e]) for e in range(n)])
+    mover0 = torch.as_tensor(((int(initial_state.player) + ply) % 2) == 0, device=device)
+    values = torch.stack([torch.where(mover0, z, -z), torch.where(mover0, -z, z)], dim=1)
+    return TensorDataset(torch.flip(planes, dims=[2]), pol, values)
+
+
 # ------------------------------------------------------------------------------------------------
 # evaluation players (ui/cli/player.py:10-76) and a head-less arena (ui/cli/arena.py:42-57)
 # ------------------------------------------------------------------------------------------------

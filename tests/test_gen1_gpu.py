@@ -320,3 +320,29 @@ def test_tree_reuse_option_bit_exact(n, sims, seed, extra):
     np.random.seed(seed)
     eps2 = list(gen.generate_episodes(HashStub("connect4", salt)))
     assert [[s.policy.tolist() for s in e.samples] for e in eps2] == [[s.policy.tolist() for s in e.samples] for e in eps]
+
+
+def test_gen1_dataset_tensors_equal_format_dataset_of_the_episodes(gen1):
+    """gen1.generate_dataset (tensors written on the GPU) against the reference's own recipe applied to the yielded
+    episodes: CNNModel._states_to_tensor (models/games/connect4/cnn.py:77-98), Connect4Model._policies_to_tensor
+    (model.py:45-51), torch.FloatTensor(values) (models/base/model.py:80) -- restated here on the host."""
+    import torch
+    from azsp import connect_state as cs
+    n, sims, seed = 12, 30, 8
+    init = cs.Config().sample_initial_state()
+    np.random.seed(seed)
+    gen = gen1.EpisodeGenerator(model=gen1.HashModel(4), num_simulations=sims, num_episodes=n, game_initial_state=init)
+    eps = list(gen.generate_episodes())
+    samples = [s for ep in eps for s in ep.samples]
+    planes = torch.zeros((len(samples), 3, 6, 7))
+    pol = torch.zeros((len(samples), 7))
+    for i, s in enumerate(samples):
+        g = torch.tensor(np.asarray(s.state.grid))
+        planes[i] = torch.stack([(g == -1).float(), (g == s.state.player).float(), (g == 1 - s.state.player).float()])
+        for a, pr in s.policy.items():
+            pol[i, a.column] = pr
+    vals = torch.FloatTensor([s.value for s in samples])
+    np.random.seed(seed)
+    ds = gen1.generate_dataset(gen)
+    got_planes, got_pol, got_vals = (t.cpu() for t in ds.tensors)
+    assert torch.equal(got_planes, planes) and torch.equal(got_pol, pol) and torch.equal(got_vals, vals)
