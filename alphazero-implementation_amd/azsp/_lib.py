@@ -81,6 +81,7 @@ SIGNATURES = {
     "azsp_record_bytes": (C.c_int32, [C.c_int32]),
     "azsp_export_dataset_device": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_int64]),
+    "azsp_probe_clock": (C.c_int, [C.c_void_p, _P(C.c_int8), C.c_int32, _P(C.c_double), _P(C.c_double)]),
     "azsp_get_stats": (C.c_int, [C.c_void_p, _P(Stats)]),
     "azsp_reset_stats": (C.c_int, [C.c_void_p]),
     "azsp_sync": (C.c_int, [C.c_void_p]),

@@ -113,6 +113,13 @@ class Engine:
         self._check(self.lib.azsp_predict(self._h, _ptr(b, C.c_int8), n, _ptr(p, C.c_float), _ptr(v, C.c_float)))
         return p, v
 
+    def probe_clock(self, boards) -> tuple[float, float]:
+        """(GHz the chip held inside one traced fp32 inference launch over `boards`, span of that launch in us)."""
+        b = self._boards_i8(boards)
+        ghz, span = C.c_double(), C.c_double()
+        self._check(self.lib.azsp_probe_clock(self._h, _ptr(b, C.c_int8), b.shape[0], C.byref(ghz), C.byref(span)))
+        return ghz.value, span.value
+
     # ---- search -------------------------------------------------------------------------------
     def run_batch(self, boards) -> dict[str, np.ndarray]:
         b = self._boards_i8(boards)

@@ -561,6 +561,19 @@ int azsp_predict(azsp_engine *e, const int8_t *boards, int32_t n, float *p_out, 
     return 0;
 }
 
+int azsp_probe_clock(azsp_engine *e, const int8_t *boards, int32_t n, double *clock_ghz, double *span_us) {
+    if (!e || !boards || n <= 0 || n > e->cfg.n_slots) return fail(AZSP_ERR_ARG, "bad argument");
+    if (e->evaluator != AZSP_EVAL_RESNET || (e->cfg.flags & AZSP_FLAG_F16_SPLIT) || e->cfg.game != AZSP_GAME_CONNECT4 ||
+        e->cfg.channels > 64 || e->cfg.channels <= 32)
+        return fail(AZSP_ERR_STATE, "the clock probe exists for the 64-channel fp32 Connect-4 network");
+    resnet_trace_next();
+    int rc = azsp_predict(e, boards, n, nullptr, nullptr);
+    if (rc) return rc;
+    resnet_trace_result(clock_ghz, span_us);
+    if (clock_ghz && *clock_ghz <= 0.0) return fail(AZSP_ERR_STATE, "no traced launch ran");
+    return 0;
+}
+
 int azsp_run_batch(azsp_engine *e, const int8_t *boards, int32_t n, int32_t *counts, float *child_w, double *prior,
                    float *root_w, int32_t *root_n) {
     if (!e || !boards || n <= 0) return fail(AZSP_ERR_ARG, "bad argument");

@@ -121,6 +121,9 @@ size_t resnet_blob_floats(int game, int blocks, int channels);
 void resnet_forward(ResNetDev *, int game, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot,
                     const int32_t *n_leaf, int max_leaves, float *out_p, float *out_v, hipStream_t s);
 double resnet_flops_per_board(const ResNetDev *);
+// diagnostics: arm the stamped instantiation for this thread's next fp32 launch; read back its clock / span
+void resnet_trace_next();
+void resnet_trace_result(double *ghz, double *span_us);
 
 // split-fp16 variant (azsp_resnet_f16.hip)
 struct ResNet16Dev;

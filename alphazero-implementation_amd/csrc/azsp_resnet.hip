@@ -764,10 +764,17 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
     return 0;
 }
 
-// AZSP_RESNET_TRACE (diagnostic): run the launch with per-workgroup phase timestamps, wait for it and print the
+// Tracing is on for a thread while AZSP_RESNET_TRACE is set or resnet_trace_next() armed it for one launch
+// (azsp_probe_clock); the last traced launch's in-kernel clock and span are kept for that probe.
+static thread_local bool g_trace_armed = false;
+static thread_local double g_trace_ghz = 0.0, g_trace_span_us = 0.0;
+void resnet_trace_next() { g_trace_armed = true; g_trace_ghz = 0.0; g_trace_span_us = 0.0; }
+void resnet_trace_result(double *ghz, double *span_us) { if (ghz) *ghz = g_trace_ghz; if (span_us) *span_us = g_trace_span_us; }
+
+// Diagnostic: run the launch with per-workgroup phase timestamps, wait for it and (AZSP_RESNET_TRACE) print the
 // mean duration of every phase over the workgroups that ran (microseconds; 100 MHz clock) to stderr.
 template <class Launch>
-static void trace_forward(const NetParams &P, int grid, Launch launch, hipStream_t s) {
+static void trace_forward(const NetParams &P, int grid, Launch launch, hipStream_t s, bool print) {
     NetParams Q = P;
     unsigned long long *d = nullptr;
     const size_t n = (size_t)grid * 64;
@@ -779,8 +786,23 @@ static void trace_forward(const NetParams &P, int grid, Launch launch, hipStream
     std::vector<unsigned long long> h(n);
     (void)hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost);
     (void)hipFree(d);
+    {   // in-kernel clock over the residual tower: core-clock ticks / 100 MHz ticks, mean over the workgroups
+        double ghz = 0;
+        int cnt = 0;
+        unsigned long long a = ~0ull, b = 0;
+        for (int w = 0; w < grid; ++w) {
+            const unsigned long long *t = &h[(size_t)w * 64];
+            if (!t[55]) continue;
+            a = t[0] < a ? t[0] : a;
+            b = t[55] > b ? t[55] : b;
+            if (t[58] > t[2]) { ghz += (double)(t[57] - t[56]) / (double)(t[58] - t[2]) * 0.1; ++cnt; }
+        }
+        g_trace_ghz = cnt ? ghz / cnt : 0.0;
+        g_trace_span_us = b > a ? (b - a) * 0.01 : 0.0;
+    }
     static int calls = 0;
-    if (++calls > 3) return;
+    static const bool verbose_probe = getenv("AZSP_PROBE_VERBOSE") != nullptr;     // print armed (warm) launches too
+    if (!(print && ++calls <= 3) && !(verbose_probe && !print)) return;
     double sum[64] = {};
     unsigned long long t_min = ~0ull, t_max = 0;
     int ran = 0;
@@ -825,12 +847,14 @@ static void launch_forward(const NetParams &P, const u64 *mine, const u64 *their
     }
     const int grid = (max_leaves + TB - 1) / TB;
     if constexpr (std::is_same<G, Connect4>::value && NT == 2 && CW == 1) {     // traced instantiations: the 64-channel Connect-4 kernels
-        static const bool trace = getenv("AZSP_RESNET_TRACE") != nullptr;
-        if (trace) {
+        static const bool trace_env = getenv("AZSP_RESNET_TRACE") != nullptr;
+        const bool armed = g_trace_armed;
+        g_trace_armed = false;
+        if (trace_env || armed) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT, MT, PF, CW, RW, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             trace_forward(P, grid, [&](const NetParams &Q) {
-                hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW, true>), dim3(grid), dim3(64 * RW * CW), lds, s, Q, mine, theirs, leaf_slot, n_leaf, out_p, out_v); }, s);
+                hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW, true>), dim3(grid), dim3(64 * RW * CW), lds, s, Q, mine, theirs, leaf_slot, n_leaf, out_p, out_v); }, s, trace_env);
             return;
         }
     }
