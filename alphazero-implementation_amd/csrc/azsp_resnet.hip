@@ -51,7 +51,9 @@ struct ResNetDev {
     size_t conv_w_stride, conv_b_stride;
     double flops_per_board = 0;
     ResNet16Dev *f16 = nullptr;   // split-fp16 variant (AZSP_FLAG_F16_SPLIT)
-    int32_t *d_perm = nullptr;    // row order of the tap-skipping Connect-4 kernels
+    int32_t *d_perm = nullptr;    // [2][256] row orders of the tap-skipping Connect-4 kernels: 4x1 and 2x2 wave grids
+    size_t o_conv_w4 = 0;         // quad-k-step copy of the conv weights (64-channel Connect-4 nets)
+    bool has_w4 = false;
 };
 
 struct NetParams {
@@ -59,6 +61,8 @@ struct NetParams {
     int conv_w_stride, conv_b_stride, blocks;
     unsigned long long *dbg;      // diagnostic phase timestamps (AZSP_RESNET_TRACE), else nullptr
     const int32_t *perm;          // [256] GEMM row -> board-cell row of the tap-skipping row order (see build_row_order)
+    const float *conv_w4;         // conv weights as [tap][s / 4][column tile][lane][4 k-steps] (one 16-byte load per lane
+                                  // feeds four k-steps of a wave that owns ONE column tile), else nullptr
 };
 // phase timestamp of wave 0 of each workgroup, 100 MHz constant clock; compiled only into the TR = true
 // diagnostic instantiation (AZSP_RESNET_TRACE), the product kernels carry no stamp code
@@ -125,13 +129,55 @@ __device__ __forceinline__ void tap_mfma(f32x16 (&acc)[MT][NTW], const float *co
     }
 }
 
+// One tap for a wave that owns MT row tiles and ONE column tile: the weights of four k-steps come in one 16-byte
+// load per lane (layout [s / 4][column tile][lane][4]), i.e. one vector-memory instruction per 4 * MT MFMAs.  A global
+// load in the MFMA stream costs matrix-pipe time that a second resident wave does not win back (measured with
+// tools/probe/mfma_rate.hip: 8 B per k-step -> 88 % of the pipe with two waves per SIMD, 16 B per four k-steps -> 100 %).
+// MASK < 0: `rt` (wave-uniform) says which row tiles take part.
+template <int MT, int S, int NT, int MASK>
+__device__ __forceinline__ void tap_mfma_quad(f32x16 (&acc)[MT][1], const float *const (&arow)[MT], const float *wq, uint32_t rt) {
+#pragma unroll
+    for (int s = 0; s < S; s += 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(wq + (size_t)(s / 4) * NT * 64 * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float b = k == 0 ? t.x : (k == 1 ? t.y : (k == 2 ? t.z : t.w));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (MASK >= 0 ? ((MASK >> mt) & 1) != 0 : ((rt >> mt) & 1u) != 0)
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[mt][2 * (s + k)], b, acc[mt][0], 0, 0, 0);
+            }
+        }
+    }
+}
+
 // `need[mt]` (wave-uniform): taps for which at least one row of row tile mt has an on-board input.  The other
 // taps multiply an all-zero A tile -- adding exactly 0 -- and are skipped (SK kernels order their rows so that
 // whole row tiles share their off-board taps; everywhere else every tap is needed by some row).
 template <class G, int MT, int NTW, int TAPS, int S, int PF, int WST = NTW, bool SK = false>
 __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *__restrict__ wl, const float *act,
                                           const int (&ridx)[MT], const uint32_t (&vmask)[MT], int stride, int zero_idx,
-                                          int lane, const uint32_t (&need)[MT]) {
+                                          int lane, const uint32_t (&need)[MT], const float *__restrict__ wq = nullptr) {
+    if constexpr (PF == 0 && SK && MT == 4 && NTW == 1 && TAPS == 9) {
+        // 2 x 2 wave grid: four row tiles, one column tile; wq = this wave's column of the quad-step weights
+        for (int tap = 0; tap < 9; ++tap) {
+            uint32_t rt = 0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) rt |= ((need[mt] >> tap) & 1u) << mt;
+            if (!rt) continue;
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const float *arow[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                arow[mt] = act + (((vmask[mt] >> tap) & 1u) ? ridx[mt] + (dy * G::COLS + dx) * stride : zero_idx);
+            const float *wt = wq + (size_t)tap * (S / 4) * WST * 64 * 4;
+            if (rt == 0xFu) tap_mfma_quad<MT, S, WST, 0xF>(acc, arow, wt, rt);
+            else if (rt == 0xEu) tap_mfma_quad<MT, S, WST, 0xE>(acc, arow, wt, rt);
+            else if (rt == 0xDu) tap_mfma_quad<MT, S, WST, 0xD>(acc, arow, wt, rt);
+            else tap_mfma_quad<MT, S, WST, -1>(acc, arow, wt, rt);        // partly filled workgroups
+        }
+        return;
+    }
     if constexpr (PF == 0 && SK && MT == 2) {
         for (int tap = 0; tap < TAPS; ++tap) {
             const int t9 = (TAPS == 9) ? tap : 4;
@@ -221,7 +267,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     static_assert(NT % CW == 0, "column tiles must divide over the column waves");
     constexpr int ZERO_IDX = WG_ROWS * STRIDE;
     // tap skipping: 6 Connect-4 boards per workgroup in the row order of build_row_order()
-    constexpr bool SK = std::is_same<G, Connect4>::value && MT == 2 && RW == 4 && PF == 0;
+    constexpr bool SK = std::is_same<G, Connect4>::value && PF == 0 && ((MT == 2 && RW == 4) || (MT == 4 && RW == 2 && CW == NT));
     extern __shared__ float smem[];
     float *act = smem;                             // [WG_ROWS + 1][STRIDE]
     constexpr int AP = G::AP;                      // actions padded to a multiple of 8
@@ -349,7 +395,8 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[mt][nt][v] = second ? xres[mt][nt][v] + bias : bias;   // x += residual
         }
-        conv_mfma<G, MT, NTW, 9, S, PF, NT, SK>(acc, wl + wc * NTW, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane, need);
+        conv_mfma<G, MT, NTW, 9, S, PF, NT, SK>(acc, wl + wc * NTW, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane, need,
+                                                (MT == 4 && P.conv_w4) ? P.conv_w4 + (size_t)layer * P.conv_w_stride + ((size_t)wc * 64 + lane) * 4 : nullptr);
         if (layer < 16) STAMP(3 + 3 * layer);
         __syncthreads();                               // every wave is done reading the layer input
         if (layer < 16) STAMP(4 + 3 * layer);
@@ -374,16 +421,27 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
         }
     }
     // ---- heads: policy conv1x1(C->32)+BN+ReLU (resnet.py:56-59), value conv3x3(C->3)+BN+ReLU (:65-68)
-    f32x16 accp[MT][1];
+    // The policy conv is ONE 32-channel column tile.  Where the row tiles of a row group divide evenly over its column
+    // waves each takes its share; otherwise the first column wave computes all of them.
+    constexpr int PSPLIT = (MT % CW == 0) ? CW : 1, PMT = MT / PSPLIT;
+    const int pt0 = PSPLIT > 1 ? wc * PMT : 0;             // first row tile (of this wave's row group) handled here
+    const bool pol_here = PSPLIT > 1 || wc == 0;
+    f32x16 accp[PMT][1];
+    int pridx[PMT];
+    uint32_t pvmask[PMT], pneed[PMT];
     {
         const float bp = P.pol_b[lane & 31];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int i = 0; i < PMT; ++i) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) accp[mt][0][v] = bp;
+            for (int v = 0; v < 16; ++v) accp[i][0][v] = bp;
+            pridx[i] = ridx[0]; pvmask[i] = vmask[0]; pneed[i] = need[0];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) if (mt == pt0 + i) { pridx[i] = ridx[mt]; pvmask[i] = vmask[mt]; pneed[i] = need[mt]; }
+        }
     }
-    if (wc == 0)      // one 32-channel tile: the first column wave of each row group computes it
-        conv_mfma<G, MT, 1, 1, S, PF, 1, SK>(accp, P.pol_w, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane, need);
+    if (pol_here)
+        conv_mfma<G, PMT, 1, 1, S, PF, 1, false>(accp, P.pol_w, act, pridx, pvmask, STRIDE, ZERO_IDX + half, lane, pneed);
     STAMP(51);
     // The value conv has 3 output channels.  As a 32-wide MFMA tile it would cost +5.8 % MFMA time for 0.6 % of the
     // FLOPs; on the vector ALU it took 16 us of a 370 us workgroup (scalar weight loads and LDS reads sharing one
@@ -392,7 +450,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     // instruction; every cell's sum is a fixed-order fma chain per kernel row (batch-invariant).
     // Operand layout (probed on gfx950): A row i of block b from lane 4b+i, B column j from lane 4b+j,
     // D[i][j] in VGPR i of lane 4b+j.
-    constexpr bool VMFMA = (CW == 1) && ((RW * MT) % 2 == 0);
+    constexpr bool VMFMA = (WG_ROWS % 64 == 0) && (RW * CW * 64 >= WG_ROWS);
     float hv0 = 0.0f, hv1 = 0.0f, hv2 = 0.0f;
     if constexpr (VMFMA) {
         constexpr int NCHUNK = WG_ROWS / 64;           // 64-row chunks; wave w owns chunk w
@@ -475,11 +533,11 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     __syncthreads();
     // policy-head activations over the (now dead) tower activations, value-head ones beside them
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int i = 0; i < PMT; ++i)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int row = lds_row(wave * WROWS + mt * 32 + cd_row(v, lane));
-            if (wc == 0) act[row * STRIDE + (lane & 31)] = fmaxf(accp[mt][0][v], 0.0f);
+            const int row = lds_row(wave * WROWS + (pt0 + i) * 32 + cd_row(v, lane));
+            if (pol_here) act[row * STRIDE + (lane & 31)] = fmaxf(accp[i][0][v], 0.0f);
         }
     if (!VMFMA && tid < TB * CELLS) {
         hval[tid * 4 + 0] = fmaxf(hv0, 0.0f);
@@ -649,6 +707,12 @@ static void build_row_order(int32_t *perm) {
         for (int i = 0; i < 32; ++i) perm[w * 64 + i] = (*special[w])[i];
         for (int i = 0; i < 32; ++i) perm[w * 64 + 32 + i] = interior[w * 32 + i];
     }
+    // second table: 2 x 2 wave grid, a row group = 4 row tiles: [left, right, interior, interior | top, bottom, interior, interior]
+    int32_t *q = perm + 256;
+    for (int grp = 0; grp < 2; ++grp) {
+        for (int k = 0; k < 2; ++k) for (int i = 0; i < 32; ++i) q[grp * 128 + k * 32 + i] = (*special[grp * 2 + k])[i];
+        for (int i = 0; i < 64; ++i) q[grp * 128 + 64 + i] = interior[grp * 64 + i];
+    }
 }
 
 ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
@@ -665,6 +729,7 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
     n->conv_b_stride = g.Cp;
     n->o_conv_w = reserve(n->conv_w_stride * 2 * blocks);
     n->o_conv_b = reserve(n->conv_b_stride * 2 * blocks);
+    if (game == 0 && g.NT == 2) { n->has_w4 = true; n->o_conv_w4 = reserve(n->conv_w_stride * 2 * blocks); }
     n->o_pol_w = reserve((size_t)g.S * 64);
     n->o_pol_b = reserve(32);
     n->o_val_w = reserve((size_t)9 * g.Cp * 4);
@@ -678,7 +743,7 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
     n->blob_floats = off;
     if (hipMalloc((void **)&n->d_blob, off * sizeof(float)) != hipSuccess) { delete n; return nullptr; }
     if (game == 0) {
-        int32_t perm[256];
+        int32_t perm[512];
         build_row_order(perm);
         if (hipMalloc((void **)&n->d_perm, sizeof perm) != hipSuccess ||
             hipMemcpy(n->d_perm, perm, sizeof perm, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(n->d_blob); delete n; return nullptr; }
@@ -727,6 +792,16 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
         ConvBN c = take_conv_bn(p, g.C, g.C, 3);
         fold(c, w, b);
         permute_conv(w, g.C, g.C, 3, g.S, g.NT, host.data() + n->o_conv_w + (size_t)l * n->conv_w_stride);
+        if (n->has_w4) {            // [tap][s / 4][nt][lane][s & 3] from [tap][s][lane][nt]
+            const float *src = host.data() + n->o_conv_w + (size_t)l * n->conv_w_stride;
+            float *dst = host.data() + n->o_conv_w4 + (size_t)l * n->conv_w_stride;
+            for (int tap = 0; tap < 9; ++tap)
+                for (int sidx = 0; sidx < g.S; ++sidx)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int nt = 0; nt < g.NT; ++nt)
+                            dst[((((size_t)tap * (g.S / 4) + sidx / 4) * g.NT + nt) * 64 + lane) * 4 + (sidx & 3)] =
+                                src[(((size_t)tap * g.S + sidx) * 64 + lane) * g.NT + nt];
+        }
         for (int o = 0; o < g.C; ++o) host[n->o_conv_b + (size_t)l * n->conv_b_stride + o] = b[o];
     }
     {
@@ -846,7 +921,7 @@ static void launch_forward(const NetParams &P, const u64 *mine, const u64 *their
         attr_set[dev] = true;
     }
     const int grid = (max_leaves + TB - 1) / TB;
-    if constexpr (std::is_same<G, Connect4>::value && NT == 2 && CW == 1) {     // traced instantiations: the 64-channel Connect-4 kernels
+    if constexpr (std::is_same<G, Connect4>::value && NT == 2 && (CW == 1 || MT == 4)) {     // traced instantiations: the 64-channel Connect-4 kernels
         static const bool trace_env = getenv("AZSP_RESNET_TRACE") != nullptr;
         const bool armed = g_trace_armed;
         g_trace_armed = false;
@@ -877,6 +952,7 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
     P.blocks = n->g.blocks;
     P.dbg = nullptr;
     P.perm = n->d_perm;
+    P.conv_w4 = n->has_w4 ? d + n->o_conv_w4 : nullptr;
     if (game == 2) {       // Gomoku 9x9: 3 boards (243 rows) per workgroup up to 64 channels, 1 board (81 of 128 rows) above
 #define FWG(NTV, MTV, PFV) launch_forward<Gomoku9, NTV, MTV, PFV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
         // wide nets: one board (81 rows -> 3 row tiles) per workgroup, one wave per 32-channel column tile
@@ -907,7 +983,13 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
         // epilogues and the weight stream, not by the MFMA chain; kept as a knob, off by default.
         if (mt == 1 && cw_env == 2) { launch_forward<Connect4, 2, 1, 1, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }
         if (mt == 1) { if (pf == 0 || (pf < 0 && !small)) FWD(2, 1, 0); else FWD(2, 1, 1); }
-        else { if (pf == 1) FWD(2, 2, 1); else FWD(2, 2, 0); }
+        else {
+            // 2 x 2 wave grid (4 row tiles x 1 column tile per wave, weights 16 B per four k-steps) unless AZSP_RESNET_GRID=4x1
+            static const bool grid41 = [] { const char *e = getenv("AZSP_RESNET_GRID"); return e && !strcmp(e, "4x1"); }();
+            if (pf == 1) FWD(2, 2, 1);
+            else if (grid41 || !P.conv_w4) FWD(2, 2, 0);
+            else { NetParams Q = P; Q.perm = P.perm + 256; launch_forward<Connect4, 2, 4, 0, 2, 2>(Q, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); }
+        }
     }
     else if (n->g.NT == 3) { if (pf == 0) FWD(3, 1, 0); else FWD(3, 1, 1); }
     // (splitting the four column tiles of a 128-channel net over four waves for small batches was measured:
