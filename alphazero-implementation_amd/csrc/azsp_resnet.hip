@@ -254,7 +254,7 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
 __device__ __forceinline__ int cd_row(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
 
 template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4, bool TR = false>
-__global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 && NT <= 2 ? 3 : (RW * CW > 8 ? RW * CW / 4 : (RW * CW == 8 && MT == 2 && RW == 4 ? 1 : 2)))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
+__global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 && NT <= 2 ? 3 : (RW * CW > 8 ? RW * CW / 4 : (RW * CW == 8 && RW * MT == 8 ? 1 : 2)))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
                                                          const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
                                                          float *__restrict__ out_p, float *__restrict__ out_v) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
@@ -729,7 +729,7 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
     n->conv_b_stride = g.Cp;
     n->o_conv_w = reserve(n->conv_w_stride * 2 * blocks);
     n->o_conv_b = reserve(n->conv_b_stride * 2 * blocks);
-    if (game == 0 && g.NT == 2) { n->has_w4 = true; n->o_conv_w4 = reserve(n->conv_w_stride * 2 * blocks); }
+    if (game == 0 && (g.NT == 2 || g.NT == 4)) { n->has_w4 = true; n->o_conv_w4 = reserve(n->conv_w_stride * 2 * blocks); }
     n->o_pol_w = reserve((size_t)g.S * 64);
     n->o_pol_b = reserve(32);
     n->o_val_w = reserve((size_t)9 * g.Cp * 4);
@@ -999,7 +999,13 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
         // large batches: 6 boards per workgroup on 8 waves (4 row groups x 2 column groups), one workgroup per CU, so
         // that the tap-skipping row order applies; small batches keep 3 boards per 4-wave workgroup
         static const int wide6 = [] { const char *e = getenv("AZSP_RESNET_WIDE6"); return e ? atoi(e) : 1; }();
-        if (wide6 && !small) launch_forward<Connect4, 4, 2, 0, 2, 4>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+        static const bool grid42 = [] { const char *e = getenv("AZSP_RESNET_GRID"); return e && !strcmp(e, "4x2"); }();
+        if (wide6 && !small && !grid42 && P.conv_w4) {      // 2 row groups x 4 column waves, 4 row tiles x 1 column tile each
+            NetParams Q = P;
+            Q.perm = P.perm + 256;
+            launch_forward<Connect4, 4, 4, 0, 4, 2>(Q, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+        }
+        else if (wide6 && !small) launch_forward<Connect4, 4, 2, 0, 2, 4>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
         else if (pf == 0) FWD(4, 1, 0); else FWD(4, 1, 1);
     }
     // 192 / 256 channels: 3 boards (128 rows) per workgroup, 2 row groups x NT/2 column groups of waves
