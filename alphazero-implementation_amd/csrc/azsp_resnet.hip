@@ -158,8 +158,9 @@ template <class G, int MT, int NTW, int TAPS, int S, int PF, int WST = NTW, bool
 __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *__restrict__ wl, const float *act,
                                           const int (&ridx)[MT], const uint32_t (&vmask)[MT], int stride, int zero_idx,
                                           int lane, const uint32_t (&need)[MT], const float *__restrict__ wq = nullptr) {
-    if constexpr (PF == 0 && SK && MT == 4 && NTW == 1 && TAPS == 9) {
-        // 2 x 2 wave grid: four row tiles, one column tile; wq = this wave's column of the quad-step weights
+    if constexpr (PF == 0 && NTW == 1 && TAPS == 9 && WST > 1) {
+      if (wq != nullptr) {
+        // waves that own ONE column tile: wq = this wave's column of the quad-step weights
         for (int tap = 0; tap < 9; ++tap) {
             uint32_t rt = 0;
 #pragma unroll
@@ -171,12 +172,13 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
             for (int mt = 0; mt < MT; ++mt)
                 arow[mt] = act + (((vmask[mt] >> tap) & 1u) ? ridx[mt] + (dy * G::COLS + dx) * stride : zero_idx);
             const float *wt = wq + (size_t)tap * (S / 4) * WST * 64 * 4;
-            if (rt == 0xFu) tap_mfma_quad<MT, S, WST, 0xF>(acc, arow, wt, rt);
-            else if (rt == 0xEu) tap_mfma_quad<MT, S, WST, 0xE>(acc, arow, wt, rt);
-            else if (rt == 0xDu) tap_mfma_quad<MT, S, WST, 0xD>(acc, arow, wt, rt);
+            if (rt == (1u << MT) - 1u) tap_mfma_quad<MT, S, WST, (1 << MT) - 1>(acc, arow, wt, rt);
+            else if (MT == 4 && rt == 0xEu) tap_mfma_quad<MT, S, WST, 0xE>(acc, arow, wt, rt);
+            else if (MT == 4 && rt == 0xDu) tap_mfma_quad<MT, S, WST, 0xD>(acc, arow, wt, rt);
             else tap_mfma_quad<MT, S, WST, -1>(acc, arow, wt, rt);        // partly filled workgroups
         }
         return;
+      }
     }
     if constexpr (PF == 0 && SK && MT == 2) {
         for (int tap = 0; tap < TAPS; ++tap) {
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
                 for (int v = 0; v < 16; ++v) acc[mt][nt][v] = second ? xres[mt][nt][v] + bias : bias;   // x += residual
         }
         conv_mfma<G, MT, NTW, 9, S, PF, NT, SK>(acc, wl + wc * NTW, act, ridx, vmask, STRIDE, ZERO_IDX + half, lane, need,
-                                                (MT == 4 && P.conv_w4) ? P.conv_w4 + (size_t)layer * P.conv_w_stride + ((size_t)wc * 64 + lane) * 4 : nullptr);
+                                                (CW == NT && P.conv_w4) ? P.conv_w4 + (size_t)layer * P.conv_w_stride + ((size_t)wc * 64 + lane) * 4 : nullptr);
         if (layer < 16) STAMP(3 + 3 * layer);
         __syncthreads();                               // every wave is done reading the layer input
         if (layer < 16) STAMP(4 + 3 * layer);
@@ -982,6 +984,8 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
         // 0.201 vs 0.189 ms per launch at 100 boards -- the single-workgroup latency floor is set by barriers,
         // epilogues and the weight stream, not by the MFMA chain; kept as a knob, off by default.
         if (mt == 1 && cw_env == 2) { launch_forward<Connect4, 2, 1, 1, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }
+        // (a 2 x 2 grid with quad-step weight loads was also measured for small batches: 0.200 vs 0.183 ms per 100-board
+        //  launch -- the explicit double-buffered stream of the 4 x 1 grid hides more latency where one workgroup owns a CU)
         if (mt == 1) { if (pf == 0 || (pf < 0 && !small)) FWD(2, 1, 0); else FWD(2, 1, 1); }
         else {
             // 2 x 2 wave grid (4 row tiles x 1 column tile per wave, weights 16 B per four k-steps) unless AZSP_RESNET_GRID=4x1
