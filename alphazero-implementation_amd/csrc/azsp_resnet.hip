@@ -984,6 +984,7 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
         // 0.201 vs 0.189 ms per launch at 100 boards -- the single-workgroup latency floor is set by barriers,
         // epilogues and the weight stream, not by the MFMA chain; kept as a knob, off by default.
         if (mt == 1 && cw_env == 2) { launch_forward<Connect4, 2, 1, 1, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }
+        if (mt == 1 && cw_env == 3) { launch_forward<Connect4, 2, 1, 0, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }   // 8 waves, quad-step weights
         // (a 2 x 2 grid with quad-step weight loads was also measured for small batches: 0.200 vs 0.183 ms per 100-board
         //  launch -- the explicit double-buffered stream of the 4 x 1 grid hides more latency where one workgroup owns a CU)
         if (mt == 1) { if (pf == 0 || (pf < 0 && !small)) FWD(2, 1, 0); else FWD(2, 1, 1); }
