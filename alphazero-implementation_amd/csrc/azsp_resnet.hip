@@ -136,6 +136,23 @@ __device__ __forceinline__ void tap_mfma(f32x16 (&acc)[MT][NTW], const float *co
 // MASK < 0: `rt` (wave-uniform) says which row tiles take part.
 template <int MT, int S, int NT, int MASK>
 __device__ __forceinline__ void tap_mfma_quad(f32x16 (&acc)[MT][1], const float *const (&arow)[MT], const float *wq, uint32_t rt) {
+    if constexpr (MT == 1) {
+        // One row tile per wave (small batches: a workgroup's serial chain sets the launch time): there are registers
+        // to spare, so ALL weight loads of the tap are issued before its first MFMA -- one L2 round trip per tap instead
+        // of one per load (measured: the compiler's own schedule waits for them one at a time, 590 ns each).
+        float4 t[S / 4];
+#pragma unroll
+        for (int q = 0; q < S / 4; ++q) t[q] = *reinterpret_cast<const float4 *>(wq + (size_t)q * NT * 64 * 4);
+#pragma unroll
+        for (int q = 0; q < S / 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float b = k == 0 ? t[q].x : (k == 1 ? t[q].y : (k == 2 ? t[q].z : t[q].w));
+                if (MASK >= 0 ? (MASK & 1) != 0 : (rt & 1u) != 0)
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[0][2 * (4 * q + k)], b, acc[0][0], 0, 0, 0);
+            }
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < S; s += 4) {
         const float4 t = *reinterpret_cast<const float4 *>(wq + (size_t)(s / 4) * NT * 64 * 4);
@@ -256,7 +273,7 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
 __device__ __forceinline__ int cd_row(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
 
 template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4, bool TR = false>
-__global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 && NT <= 2 ? 3 : (RW * CW > 8 ? RW * CW / 4 : (RW * CW == 8 && RW * MT == 8 ? 1 : 2)))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
+__global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 && NT <= 2 ? 3 : (RW * CW == 16 ? 1 : (RW * CW > 8 ? RW * CW / 4 : (RW * CW == 8 && RW * MT == 8 ? 1 : 2))))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
                                                          const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
                                                          float *__restrict__ out_p, float *__restrict__ out_v) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
@@ -971,6 +988,7 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
     //                    scheduled by the compiler (PF = 0)
     //   <= 768 boards  : latency-bound (one workgroup's serial chain): 1 row tile per wave = 3 boards per workgroup and
     //                    the explicit double-buffered weight stream (PF = 1)
+    //   <= 320 boards (64 channels) / 512 (128 channels): ONE board per workgroup, each wave one row tile x one column tile
     // AZSP_RESNET_MT / _PF / _CW / _WIDE6 override the choice for tuning.
     static const int mt_env = [] { const char *e = getenv("AZSP_RESNET_MT"); return e ? atoi(e) : 0; }();
     const int mt = mt_env ? mt_env : (max_leaves <= 768 ? 1 : 2);
@@ -984,6 +1002,13 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
         // 0.201 vs 0.189 ms per launch at 100 boards -- the single-workgroup latency floor is set by barriers,
         // epilogues and the weight stream, not by the MFMA chain; kept as a knob, off by default.
         if (mt == 1 && cw_env == 2) { launch_forward<Connect4, 2, 1, 1, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }
+        // up to ~one workgroup per CU a launch takes as long as ONE workgroup, and that time grows with the boards it
+        // holds: one board per 4-wave workgroup (2 x 2 grid, 42 of 64 rows used) -- 0.112 vs 0.185 ms for 100 boards
+        static const int tb1 = [] { const char *e = getenv("AZSP_RESNET_TB1"); return e ? atoi(e) : 320; }();
+        if (mt == 1 && tb1 && P.conv_w4 && max_leaves <= tb1) {
+            launch_forward<Connect4, 2, 1, 0, 2, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+            return;
+        }
         if (mt == 1 && cw_env == 3) { launch_forward<Connect4, 2, 1, 0, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }   // 8 waves, quad-step weights
         // (a 2 x 2 grid with quad-step weight loads was also measured for small batches: 0.200 vs 0.183 ms per 100-board
         //  launch -- the explicit double-buffered stream of the 4 x 1 grid hides more latency where one workgroup owns a CU)
@@ -1011,6 +1036,10 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
             launch_forward<Connect4, 4, 4, 0, 4, 2>(Q, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
         }
         else if (wide6 && !small) launch_forward<Connect4, 4, 2, 0, 2, 4>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+        else if (small && P.conv_w4 && max_leaves <= (getenv("AZSP_RESNET_TB1") ? atoi(getenv("AZSP_RESNET_TB1")) : 512))   // one board per 8-wave workgroup: 0.86 vs 1.88 ms (9 blocks, 100 boards)
+            launch_forward<Connect4, 4, 1, 0, 4, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+        else if (small && P.conv_w4 && getenv("AZSP_RESNET_CW") && atoi(getenv("AZSP_RESNET_CW")) == 4)   // 16 waves per 3 boards, quad-step weights
+            launch_forward<Connect4, 4, 1, 0, 4, 4>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
         else if (pf == 0) FWD(4, 1, 0); else FWD(4, 1, 1);
     }
     // 192 / 256 channels: 3 boards (128 rows) per workgroup, 2 row groups x NT/2 column groups of waves

@@ -266,7 +266,11 @@ def test_resnet_every_batch_regime_returns_the_same_bits(azsp, blocks, ch, f16):
         p_odd, v_odd = e.predict(boards[:1003])               # a partly filled last workgroup
     with _engine(azsp, "connect4", 100, 1, res_blocks=blocks, channels=ch, f16_split=f16) as e:
         e.load_resnet(blob)
-        p_small, v_small = e.predict(boards)                  # 100-board launches: small-batch variant
+        p_small, v_small = e.predict(boards)                  # 100-board launches: one board per workgroup
+    with _engine(azsp, "connect4", 700, 1, res_blocks=blocks, channels=ch, f16_split=f16) as e:
+        e.load_resnet(blob)
+        p_mid, v_mid = e.predict(boards)                      # 700-board launches: three boards per workgroup
+    assert np.array_equal(p_mid, p_big) and np.array_equal(v_mid, v_big)
     assert np.array_equal(p_perm, p_big[perm]) and np.array_equal(v_perm, v_big[perm])
     assert np.array_equal(p_odd, p_big[:1003]) and np.array_equal(v_odd, v_big[:1003])
     assert np.array_equal(p_small, p_big) and np.array_equal(v_small, v_big)
