@@ -120,6 +120,7 @@ def main() -> None:
     ap.add_argument("--groups", type=int, default=0, help="concurrent slot groups / HIP streams per GPU (0 = auto)")
     ap.add_argument("--precision", choices=["f32", "f16x2"], default="f32", help="inference arithmetic of the headline")
     ap.add_argument("--single", action="store_true", help="measure only --precision")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the in-kernel clock measurement after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--game", choices=["connect4", "gomoku9"], default="connect4",
                     help="gomoku9 = BASELINE.json configs[4]'s game (not a headline config; fp32 only, no CPU baseline)")
@@ -226,7 +227,7 @@ def main() -> None:
         }
 
     head = measure(args.precision)
-    if (args.precision == "f32" and args.game == "connect4" and 32 < args.channels <= 64 and rank == 0):
+    if (args.precision == "f32" and args.game == "connect4" and 32 < args.channels <= 64 and rank == 0 and not args.no_clock_probe):
         # The peak assumes the nominal 2.4 GHz; what the chip holds under this kernel is measured right after the timed
         # region with the stamped diagnostic instantiation: 2000 untraced launches (about 1.5 s) of 3072 mid-game
         # boards (two workgroups per CU, like the overlapping launches of the run), then one traced launch.

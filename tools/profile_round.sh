@@ -20,6 +20,6 @@ mkdir -p "$OUT"
 python3 "$R/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- python3 "$R/bench.py" --no-cpu-baseline > "$OUT/${TAG}_trace.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_fetch" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --sims 20 > "$OUT/${TAG}_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_write" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --sims 20 > "$OUT/${TAG}_write.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_fetch" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-clock-probe --sims 20 > "$OUT/${TAG}_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_write" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-clock-probe --sims 20 > "$OUT/${TAG}_write.log" 2>&1
 echo "done: $OUT/${TAG}_*"
