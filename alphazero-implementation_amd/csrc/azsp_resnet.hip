@@ -748,7 +748,7 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
     n->conv_b_stride = g.Cp;
     n->o_conv_w = reserve(n->conv_w_stride * 2 * blocks);
     n->o_conv_b = reserve(n->conv_b_stride * 2 * blocks);
-    if (game == 0 && (g.NT == 2 || g.NT == 4)) { n->has_w4 = true; n->o_conv_w4 = reserve(n->conv_w_stride * 2 * blocks); }
+    if ((game == 0 && (g.NT == 2 || g.NT == 4)) || (game == 2 && g.NT >= 3)) { n->has_w4 = true; n->o_conv_w4 = reserve(n->conv_w_stride * 2 * blocks); }
     n->o_pol_w = reserve((size_t)g.S * 64);
     n->o_pol_b = reserve(32);
     n->o_val_w = reserve((size_t)9 * g.Cp * 4);
@@ -975,11 +975,14 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
     if (game == 2) {       // Gomoku 9x9: 3 boards (243 rows) per workgroup up to 64 channels, 1 board (81 of 128 rows) above
 #define FWG(NTV, MTV, PFV) launch_forward<Gomoku9, NTV, MTV, PFV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
         // wide nets: one board (81 rows -> 3 row tiles) per workgroup, one wave per 32-channel column tile
+        // (each wave owns one column tile: weights as one 16-byte load per four k-steps; AZSP_RESNET_GQUAD=0 = the
+        //  per-k-step double-buffered stream)
+        static const bool gquad = [] { const char *e = getenv("AZSP_RESNET_GQUAD"); return !e || atoi(e) != 0; }();
         if (n->g.NT == 1) FWG(1, 2, 0); else if (n->g.NT == 2) FWG(2, 2, 0);
-        else if (n->g.NT == 3) launch_forward<Gomoku9, 3, 3, 1, 3, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
-        else if (n->g.NT == 4) launch_forward<Gomoku9, 4, 3, 1, 4, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
-        else if (n->g.NT == 6) launch_forward<Gomoku9, 6, 3, 1, 6, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
-        else launch_forward<Gomoku9, 8, 3, 1, 8, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+        else if (n->g.NT == 3) { if (gquad && P.conv_w4) launch_forward<Gomoku9, 3, 3, 0, 3, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); else launch_forward<Gomoku9, 3, 3, 1, 3, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); }
+        else if (n->g.NT == 4) { if (gquad && P.conv_w4) launch_forward<Gomoku9, 4, 3, 0, 4, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); else launch_forward<Gomoku9, 4, 3, 1, 4, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); }
+        else if (n->g.NT == 6) { if (gquad && P.conv_w4) launch_forward<Gomoku9, 6, 3, 0, 6, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); else launch_forward<Gomoku9, 6, 3, 1, 6, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); }
+        else { if (gquad && P.conv_w4) launch_forward<Gomoku9, 8, 3, 0, 8, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); else launch_forward<Gomoku9, 8, 3, 1, 8, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); }
 #undef FWG
         return;
     }
