@@ -627,3 +627,27 @@ def test_background_thread_generation_next_to_torch_training(azsp):
         lo, hi = ref["ep_offset"][e], ref["ep_offset"][e + 1]
         assert np.array_equal(np.stack([s.state for s in ep.samples]).reshape(hi - lo, -1), ref["states"][lo:hi])
         assert np.array_equal(np.stack([s.policy for s in ep.samples]), ref["policies"][lo:hi])
+
+
+def test_clock_probe_reports_a_plausible_in_kernel_clock(azsp):
+    """azsp_probe_clock: the stamped diagnostic instantiation of the fp32 kernel returns the clock held inside the
+    kernel; after a few hundred launches it must be a sane MI355X figure, and the probe must refuse engines it
+    does not cover."""
+    import torch
+    from azsp.weights import resnet_blob
+    torch.manual_seed(0)
+    blob = resnet_blob(azsp.ResNet((6, 7), 7, 4, 64))[0]
+    boards = np.stack(random_midgame_boards(oz.C4Rules(), np.random.RandomState(1), 1536, 41))
+    with _engine(azsp, "connect4", 1536, 1, res_blocks=4, channels=64) as e:
+        e.load_resnet(blob)
+        p0, v0 = e.predict(boards)
+        for _ in range(300):
+            e.predict(boards)
+        ghz, span = e.probe_clock(boards)
+        p1, v1 = e.predict(boards)
+    assert 1.5 < ghz < 2.6 and 50.0 < span < 5000.0
+    assert np.array_equal(p0, p1) and np.array_equal(v0, v1)      # the probe leaves the engine as it was
+    with _engine(azsp, "connect4", 64, 1, hash_salt=1) as e:
+        e.use_hash_evaluator()
+        with pytest.raises(Exception):
+            e.probe_clock(boards[:8])
