@@ -651,3 +651,51 @@ def test_clock_probe_reports_a_plausible_in_kernel_clock(azsp):
         e.use_hash_evaluator()
         with pytest.raises(Exception):
             e.probe_clock(boards[:8])
+
+
+def test_c_abi_rejects_bad_arguments_with_messages(azsp):
+    """Raw C-ABI calls (ctypes): wrong struct sizes, unknown ids, out-of-range slots, out-of-order calls and decided
+    initial positions come back as negative codes with a message; nothing crosses the boundary as a crash."""
+    import ctypes as C
+    from azsp import _lib as L
+    lib = L.load()
+    h = C.c_void_p()
+    good = L.Config(C.sizeof(L.Config), 0, 8, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+
+    def err():
+        return lib.azsp_last_error().decode()
+
+    bad = L.Config(C.sizeof(L.Config) - 4, 0, 8, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    assert lib.azsp_create(C.byref(bad), C.byref(h)) < 0 and "struct_size" in err()
+    for field, value, word in (("game", 9, "game"), ("n_slots", -1, "n_slots"), ("n_sims", 70000, "n_sims"),
+                               ("device", 99, "device"), ("search_rules", 7, "rule")):
+        cfg = L.Config(*[getattr(good, f) for f, _ in L.Config._fields_])
+        setattr(cfg, field, value)
+        assert lib.azsp_create(C.byref(cfg), C.byref(h)) < 0 and word in err(), (field, err())
+    cfg = L.Config(*[getattr(good, f) for f, _ in L.Config._fields_])
+    cfg.search_rules, cfg.game = L.RULES_GEN1, L.GAME_CONNECT2
+    assert lib.azsp_create(C.byref(cfg), C.byref(h)) < 0 and "Connect-4" in err()
+    cfg = L.Config(*[getattr(good, f) for f, _ in L.Config._fields_])
+    cfg.res_blocks, cfg.channels = 2, 999
+    assert lib.azsp_create(C.byref(cfg), C.byref(h)) < 0 and "geometry" in err()
+    assert lib.azsp_create(C.byref(good), C.byref(h)) == 0
+    try:
+        res = L.PlyResult()
+        u = (C.c_double * 8)()
+        assert lib.azsp_play_commit(h, -1, C.byref(res)) < 0 and "play_begin" in err()
+        assert lib.azsp_root_counts(h, (C.c_int32 * 56)()) < 0 and "before" in err()
+        assert lib.azsp_fetch_episodes(h, 0, 3, None, None, None, None, None, None, 0) < 0 and "not emitted" in err()
+        opts = L.SearchOptions(C.sizeof(L.SearchOptions), -1, 2.0, 1.0, 0.0)
+        assert lib.azsp_set_search_options(h, C.byref(opts)) < 0 and "noise_eps" in err()
+        opts = L.SearchOptions(C.sizeof(L.SearchOptions), -1, 0.0, 1.0, -3.0)
+        assert lib.azsp_set_search_options(h, C.byref(opts)) < 0 and "c_base" in err()
+        won = np.zeros((6, 7), np.int8)
+        won[5, :4] = -1                                   # the opponent already has four in a row
+        assert lib.azsp_set_initial_board(h, won.ctypes.data_as(C.POINTER(C.c_int8))) < 0 and "decided" in err()
+        boards = np.zeros((9, 42), np.int8)
+        assert lib.azsp_run_batch(h, boards.ctypes.data_as(C.POINTER(C.c_int8)), 9, None, None, None, None, None) < 0 and "exceeds" in err()
+        assert lib.azsp_set_evaluator(h, L.EVAL_RESNET, L.PREDICT_FN(), None) < 0 and "ResNet" in err()
+        assert lib.azsp_set_evaluator(h, L.EVAL_HOST, L.PREDICT_FN(), None) < 0 and "callback" in err()
+        assert lib.azsp_search(h) == 0 and lib.azsp_play(h, u, C.byref(res)) == 0 and res.ply == 0
+    finally:
+        lib.azsp_destroy(h)
