@@ -168,6 +168,18 @@ __device__ __forceinline__ void tap_mfma_quad(f32x16 (&acc)[MT][1], const float 
     }
 }
 
+// Row tile T of one tap over NQ quads of k-steps whose weights are already in registers (q0 = first quad).
+template <int MT, int NQ, int T>
+__device__ __forceinline__ void tap_block(f32x16 (&acc)[MT][1], const float *arow_t, const float4 (&t)[NQ], int q0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float b = k == 0 ? t[q].x : (k == 1 ? t[q].y : (k == 2 ? t[q].z : t[q].w));
+            acc[T][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow_t[2 * (4 * (q0 + q) + k)], b, acc[T][0], 0, 0, 0);
+        }
+}
+
 // `need[mt]` (wave-uniform): taps for which at least one row of row tile mt has an on-board input.  The other
 // taps multiply an all-zero A tile -- adding exactly 0 -- and are skipped (SK kernels order their rows so that
 // whole row tiles share their off-board taps; everywhere else every tap is needed by some row).
@@ -189,6 +201,23 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
             for (int mt = 0; mt < MT; ++mt)
                 arow[mt] = act + (((vmask[mt] >> tap) & 1u) ? ridx[mt] + (dy * G::COLS + dx) * stride : zero_idx);
             const float *wt = wq + (size_t)tap * (S / 4) * WST * 64 * 4;
+            if constexpr (MT == 4) {
+                // Eight quads (32 k-steps) of weights at a time in registers, then one straight-line block per row tile
+                // that needs the tap.  (One interleaved body per tile mask was 7 % slower to write off: the alternative
+                // bodies meeting in one loop made the compiler keep 40-60 residual registers in scratch.)
+                constexpr int NQ = 8;
+#pragma unroll
+                for (int q0 = 0; q0 < S / 4; q0 += NQ) {
+                    float4 t[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) t[q] = *reinterpret_cast<const float4 *>(wt + (size_t)(q0 + q) * WST * 64 * 4);
+                    if (rt & 4u) tap_block<MT, NQ, 2>(acc, arow[2], t, q0);
+                    if (rt & 8u) tap_block<MT, NQ, 3>(acc, arow[3], t, q0);
+                    if (rt & 1u) tap_block<MT, NQ, 0>(acc, arow[0], t, q0);
+                    if (rt & 2u) tap_block<MT, NQ, 1>(acc, arow[1], t, q0);
+                }
+                continue;
+            }
             if (rt == (1u << MT) - 1u) tap_mfma_quad<MT, S, WST, (1 << MT) - 1>(acc, arow, wt, rt);
             else if (MT == 4 && rt == 0xEu) tap_mfma_quad<MT, S, WST, 0xE>(acc, arow, wt, rt);
             else if (MT == 4 && rt == 0xDu) tap_mfma_quad<MT, S, WST, 0xD>(acc, arow, wt, rt);
