@@ -201,18 +201,18 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
             for (int mt = 0; mt < MT; ++mt)
                 arow[mt] = act + (((vmask[mt] >> tap) & 1u) ? ridx[mt] + (dy * G::COLS + dx) * stride : zero_idx);
             const float *wt = wq + (size_t)tap * (S / 4) * WST * 64 * 4;
-            if constexpr (MT == 4) {
+            if constexpr (MT > 1) {
                 // Eight quads (32 k-steps) of weights at a time in registers, then one straight-line block per row tile
-                // that needs the tap.  (One interleaved body per tile mask was 7 % slower to write off: the alternative
-                // bodies meeting in one loop made the compiler keep 40-60 residual registers in scratch.)
-                constexpr int NQ = 8;
+                // that needs the tap.  (One interleaved body per tile mask was 8-15 % slower: the alternative bodies
+                // meeting in one loop made the compiler keep 40-60 residual registers in scratch and schedule worse.)
+                constexpr int NQ = (S / 4) % 8 == 0 ? 8 : (S / 4);
 #pragma unroll
                 for (int q0 = 0; q0 < S / 4; q0 += NQ) {
                     float4 t[NQ];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) t[q] = *reinterpret_cast<const float4 *>(wt + (size_t)(q0 + q) * WST * 64 * 4);
-                    if (rt & 4u) tap_block<MT, NQ, 2>(acc, arow[2], t, q0);
-                    if (rt & 8u) tap_block<MT, NQ, 3>(acc, arow[3], t, q0);
+                    if constexpr (MT > 3) if (rt & 8u) tap_block<MT, NQ, (MT > 3 ? 3 : 0)>(acc, arow[MT > 3 ? 3 : 0], t, q0);
+                    if constexpr (MT > 2) if (rt & 4u) tap_block<MT, NQ, (MT > 2 ? 2 : 0)>(acc, arow[MT > 2 ? 2 : 0], t, q0);
                     if (rt & 1u) tap_block<MT, NQ, 0>(acc, arow[0], t, q0);
                     if (rt & 2u) tap_block<MT, NQ, 1>(acc, arow[1], t, q0);
                 }
