@@ -22,6 +22,8 @@ def means(path, counter):
 
 
 def main():
+    if len(sys.argv) not in (3, 4) or (len(sys.argv) == 4 and not sys.argv[3].endswith(".json")):
+        sys.exit(__doc__)           # (a shell glob that matches two csv files per pass once overwrote a counter file)
     fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")
     out = {}
     for k in sorted(set(fetch) | set(write)):
