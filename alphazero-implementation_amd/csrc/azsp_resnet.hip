@@ -1018,8 +1018,8 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
     // Variant selection (all variants give bitwise the same outputs; measured choices):
     //   large batches  : 2 row tiles per wave = 6 boards per workgroup, rows in the tap-skipping order, weight stream
     //                    scheduled by the compiler (PF = 0)
-    //   <= 768 boards  : latency-bound (one workgroup's serial chain): 1 row tile per wave = 3 boards per workgroup and
-    //                    the explicit double-buffered weight stream (PF = 1)
+    //   <= 768 boards  : latency-bound (one workgroup's serial chain): 3 boards per workgroup on a 2 x 2 / 2 x 4 wave grid
+    //                    (32 and 96 channels: 1 row tile per wave with the explicit double-buffered weight stream, PF = 1)
     //   <= 320 boards (64 channels) / 512 (128 channels): ONE board per workgroup, each wave one row tile x one column tile
     // AZSP_RESNET_MT / _PF / _CW / _WIDE6 override the choice for tuning.
     static const int mt_env = [] { const char *e = getenv("AZSP_RESNET_MT"); return e ? atoi(e) : 0; }();
@@ -1041,6 +1041,10 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
             launch_forward<Connect4, 2, 1, 0, 2, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
             return;
         }
+        // up to 768 boards: 3 boards per workgroup on the 2 x 2 grid (two row tiles x one column tile per wave, block path):
+        // 0.176 vs 0.188 ms for 512 boards with the double-buffered 4 x 1 stream (AZSP_RESNET_MID=0 selects that)
+        static const bool mid_old = [] { const char *e = getenv("AZSP_RESNET_MID"); return e && atoi(e) == 0; }();
+        if (mt == 1 && P.conv_w4 && !mid_old && mt_env == 0 && pf < 0) { launch_forward<Connect4, 2, 2, 0, 2, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }
         if (mt == 1 && cw_env == 3) { launch_forward<Connect4, 2, 1, 0, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }   // 8 waves, quad-step weights
         // (a 2 x 2 grid with quad-step weight loads was also measured for small batches: 0.200 vs 0.183 ms per 100-board
         //  launch -- the explicit double-buffered stream of the 4 x 1 grid hides more latency where one workgroup owns a CU)
@@ -1070,6 +1074,8 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
         else if (wide6 && !small) launch_forward<Connect4, 4, 2, 0, 2, 4>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
         else if (small && P.conv_w4 && max_leaves <= (getenv("AZSP_RESNET_TB1") ? atoi(getenv("AZSP_RESNET_TB1")) : 512))   // one board per 8-wave workgroup: 0.86 vs 1.88 ms (9 blocks, 100 boards)
             launch_forward<Connect4, 4, 1, 0, 4, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+        else if (small && P.conv_w4 && !(getenv("AZSP_RESNET_MID") && atoi(getenv("AZSP_RESNET_MID")) == 0))   // 513..768 boards: 3 boards on a 2 x 4 grid, block path (1.20 vs 1.72 ms)
+            launch_forward<Connect4, 4, 2, 0, 4, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
         else if (small && P.conv_w4 && getenv("AZSP_RESNET_CW") && atoi(getenv("AZSP_RESNET_CW")) == 4)   // 16 waves per 3 boards, quad-step weights
             launch_forward<Connect4, 4, 1, 0, 4, 4>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
         else if (pf == 0) FWD(4, 1, 0); else FWD(4, 1, 1);
