@@ -182,7 +182,7 @@ static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
         case AZSP_EVAL_RESNET: {
             if (!e->net || !e->net_loaded) return fail(AZSP_ERR_STATE, "ResNet evaluator selected but no weights loaded (azsp_load_resnet)");
             EventPair *p = ev_begin(e, EV_INFER, st);
-            resnet_forward(e->net, game, v.leaf_mine, v.leaf_theirs, v.leaf_slot + v.lo, v.n_leaf + v.grp, v.n_act,
+            resnet_forward(e->net, game, v.leaf_mine, v.leaf_theirs, v.leaf_slot + v.lo, v.nl, v.n_act,
                            v.eval_p + (size_t)v.lo * PSTRIDE, v.eval_v + v.lo, st);   // ResNet: Connect-4 only, AP == PSTRIDE
             ev_end(p, st);
             e->stats.infer_launches++;
@@ -193,7 +193,7 @@ static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
             if (v.lo != 0) return fail(AZSP_ERR_STATE, "host evaluator needs a single slot group");
             const int A = e->gi.A, cells = e->gi.cells, AP = e->gi.AP;
             launch_leaf_cells(game, v, e->d_cells, st);
-            HIP_TRY(hipMemcpyAsync(e->h_nleaf, v.n_leaf, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(e->h_nleaf, v.nl, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             const int m = *e->h_nleaf;
             if (m <= 0) return 0;
@@ -225,6 +225,8 @@ static int search(azsp_engine *e, int n_act) {
     for (int k = 0; k < G; ++k) {
         gv[k] = e->v;
         gv[k].grp = k;
+        gv[k].nl = e->v.n_leaf + 2 * k;
+        gv[k].nl_other = gv[k].nl + 1;
         gv[k].lo = (int)((long long)n_act * k / G);
         gv[k].n_act = (int)((long long)n_act * (k + 1) / G) - gv[k].lo;
     }
@@ -238,13 +240,32 @@ static int search(azsp_engine *e, int n_act) {
         launch_compact(gv[k], st);
         int rc = evaluate_leaves(e, gv[k], st);
         if (rc) return rc;
-        launch_expand(game, gv[k], st);
     }
-    // rule set 1: the root expansion above was simulation 1 (search.py:66-91)
+    // rule set 1: the root expansion is simulation 1 (search.py:66-91)
     const int descents = e->cfg.search_rules == AZSP_RULES_GEN1 ? e->cfg.n_sims - 1 : e->cfg.n_sims;
+    // Device evaluators: expansion of round s-1 and descent of round s run as ONE launch that appends its leaves with a
+    // wave-level atomic (two launches per round).  The host-callback evaluator keeps the stable, slot-ordered
+    // select -> compact -> evaluate -> expand sequence (the reference hands its leaves over in slot order).
+    static const bool fused_env = [] { const char *x = getenv("AZSP_FUSED_TREE"); return !x || atoi(x) != 0; }();
+    const bool fused = fused_env && e->evaluator != AZSP_EVAL_HOST;
+    if (!fused)
+        for (int k = 0; k < G; ++k) launch_expand(game, gv[k], e->gstream[k]);
     for (int s = 0; s < descents; ++s) {
         for (int k = 0; k < G; ++k) {
             hipStream_t st = e->gstream[k];
+            if (fused) {
+                // round s + 1 fills the group's counter of parity (s + 1) & 1; the root stage used parity 0
+                View w = gv[k];
+                w.nl = e->v.n_leaf + 2 * k + ((s + 1) & 1);
+                w.nl_other = e->v.n_leaf + 2 * k + (s & 1);
+                EventPair *p = ev_begin(e, EV_SELECT, st);
+                launch_expand_select(game, w, st);
+                ev_end(p, st);
+                e->stats.select_launches++;
+                int rc = evaluate_leaves(e, w, st);
+                if (rc) return rc;
+                continue;
+            }
             EventPair *p = ev_begin(e, EV_SELECT, st);
             launch_select(game, gv[k], st);
             launch_compact(gv[k], st);
@@ -258,6 +279,16 @@ static int search(azsp_engine *e, int n_act) {
             e->stats.expand_launches++;
         }
     }
+    if (fused)
+        for (int k = 0; k < G; ++k) {           // the last round's leaves (or, with no descent at all, the roots)
+            View w = gv[k];
+            w.nl = e->v.n_leaf + 2 * k + (descents & 1);
+            w.nl_other = e->v.n_leaf + 2 * k + ((descents + 1) & 1);
+            EventPair *p = ev_begin(e, EV_EXPAND, e->gstream[k]);
+            launch_expand(game, w, e->gstream[k]);
+            ev_end(p, e->gstream[k]);
+            e->stats.expand_launches++;
+        }
     for (int k = 1; k < G; ++k) {
         HIP_TRY(hipEventRecord(e->ev_join[k], e->gstream[k]));
         HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join[k], 0));
@@ -405,9 +436,12 @@ static int create_impl(azsp_engine *e) {
     HIP_TRY(hipMemset(v.next_root, 0xff, (size_t)N * sizeof(int32_t)));
     DEV_ALLOC(v.path, (size_t)N * v.D); DEV_ALLOC(v.path_len, N); DEV_ALLOC(v.leaf_node, N);
     DEV_ALLOC(v.leaf_mine, (size_t)N * W); DEV_ALLOC(v.leaf_theirs, (size_t)N * W); DEV_ALLOC(v.pending, N);
-    DEV_ALLOC(v.leaf_slot, N); DEV_ALLOC(v.n_leaf, MAX_GROUPS);
+    DEV_ALLOC(v.leaf_slot, N); DEV_ALLOC(v.n_leaf, MAX_GROUPS * 2); DEV_ALLOC(v.leaf_index, N);
+    v.nl = v.n_leaf;
+    v.nl_other = v.n_leaf + 1;
+    HIP_TRY(hipMemset(v.leaf_index, 0, (size_t)N * sizeof(int32_t)));
     HIP_TRY(hipMemset(v.leaf_slot, 0, (size_t)N * sizeof(int32_t)));
-    HIP_TRY(hipMemset(v.n_leaf, 0, MAX_GROUPS * sizeof(int32_t)));
+    HIP_TRY(hipMemset(v.n_leaf, 0, MAX_GROUPS * 2 * sizeof(int32_t)));
     DEV_ALLOC(v.eval_p, (size_t)N * AP); DEV_ALLOC(v.eval_v, N);
     e->tab_len = v.reuse ? (S + 1) * gi.max_plies + 2 : S + 2;    // largest N_parent + 1 a search can see
     DEV_ALLOC(e->d_sqrt, e->tab_len); DEV_ALLOC(e->d_ctab, e->tab_len); DEV_ALLOC(e->d_expl, e->tab_len);

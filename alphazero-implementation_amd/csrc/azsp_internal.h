@@ -51,7 +51,10 @@ struct View {
     u64     *leaf_mine, *leaf_theirs;   // [n_slots][W] canonical position at the leaf
     uint8_t *pending;       // [n_slots] leaf awaits evaluation
     int32_t *leaf_slot;     // [n_slots] per group, at offset lo: compacted (slot order) list of pending slots
-    int32_t *n_leaf;        // [MAX_GROUPS]
+    int32_t *n_leaf;        // [MAX_GROUPS][2] leaf counters (two per group: the fused tree kernel alternates them)
+    int32_t *nl;            // the counter this launch reads / fills: n_leaf + grp * 2 + parity
+    int32_t *nl_other;      // the group's other counter (the fused kernel zeroes it for the round after)
+    int32_t *leaf_index;    // [n_slots] compacted index (absolute, lo-based) of the slot's pending leaf
     float   *eval_p;        // [n_slots][AP] evaluator output (AP = A padded to 8), at offset lo, indexed by compacted leaf
     float   *eval_v;        // [n_slots]
     const double *sqrt_tab; // [n_sims + 2, or a whole game's simulations with tree reuse] host-computed sqrt(N): bit-identical to math.sqrt
@@ -97,6 +100,7 @@ void launch_select(int game, const View &v, hipStream_t s);
 void launch_compact(const View &v, hipStream_t s);
 void launch_eval_hash(int game, const View &v, uint64_t salt, hipStream_t s);
 void launch_expand(int game, const View &v, hipStream_t s);
+void launch_expand_select(int game, const View &v, hipStream_t s);      // expand of round r-1 fused with select of round r
 void launch_leaf_cells(int game, const View &v, int8_t *dst, hipStream_t s);
 void launch_finish(int game, const View &v, const double *uniforms, hipStream_t s);
 void launch_count_done(const View &v, int32_t *out, hipStream_t s);

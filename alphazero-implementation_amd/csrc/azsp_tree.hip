@@ -71,6 +71,7 @@ __device__ __forceinline__ int red_add(int x) {
 template <class G, int R>
 __global__ void k_root_prepare(View v) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) v.nl_other[0] = 0;             // the first fused expand+select round appends to the other counter
     if (g >= v.n_act) return;
     g += v.lo;
     size_t base = (size_t)g * v.C;
@@ -105,14 +106,16 @@ __global__ void k_root_prepare(View v) {
 // ------------------------------------------------------------------------------------------------
 // selection: PUCT descent to the first unexpanded node, leaf step, terminal test
 // ------------------------------------------------------------------------------------------------
-template <class G, int R>
-__global__ __launch_bounds__(64) void k_select(View v) {
+// APPEND: the non-terminal leaves are appended to the group's leaf list here (one atomic per wavefront; the order of
+// the list does not matter to the device evaluators, whose outputs do not depend on a position's place in the batch)
+// instead of by the stable k_compact pass that the host-callback evaluator needs.
+template <class G, int R, bool APPEND>
+__device__ __forceinline__ void select_body(const View &v, int *s_path) {
     using WT = typename std::conditional<R == 0, float, double>::type;
     const WT *wsum_r = R == 0 ? (const WT *)v.wsum : (const WT *)v.wsum_d;
     WT *wsum_w = R == 0 ? (WT *)v.wsum : (WT *)v.wsum_d;
     constexpr int A = G::A, LPG = G::LPG, APL = G::APL, GPW = 64 / LPG;
     static_assert(APL * LPG >= A, "every action needs a lane slot");
-    extern __shared__ int s_path[];                 // [GPW games][D]
     const int lane = threadIdx.x & (LPG - 1);
     const int grp = threadIdx.x / LPG;
     const int gl = blockIdx.x * GPW + grp;
@@ -244,6 +247,31 @@ __global__ __launch_bounds__(64) void k_select(View v) {
             atomicAdd(&v.counters[2], (unsigned long long)L);
         }
     }
+    if constexpr (APPEND) {
+        const bool mine_to_add = live && term == TERM_NONE && lane == 0;
+        const unsigned long long bal = __ballot(mine_to_add);
+        const int cnt = __popcll(bal);
+        int base_j = 0;
+        if (cnt > 0) {
+            const int leader = __ffsll((long long)bal) - 1;
+            if ((int)threadIdx.x == leader) {
+                base_j = atomicAdd(v.nl, cnt);
+                atomicAdd(&v.counters[0], (unsigned long long)cnt);
+            }
+            base_j = __shfl(base_j, leader, 64);
+        }
+        if (mine_to_add) {
+            const int j = v.lo + base_j + __popcll(bal & ((1ull << threadIdx.x) - 1ull));
+            v.leaf_slot[j] = g;
+            v.leaf_index[g] = j;
+        }
+    }
+}
+
+template <class G, int R>
+__global__ __launch_bounds__(64) void k_select(View v) {
+    extern __shared__ int s_path[];                 // [GPW games][D]
+    select_body<G, R, false>(v, s_path);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -266,9 +294,9 @@ __global__ __launch_bounds__(1024) void k_compact(View v) {
     }
     int pos = v.lo + s_sum[t] - c;
     for (int g = lo; g < hi; ++g)
-        if (v.pending[g]) v.leaf_slot[pos++] = g;
+        if (v.pending[g]) { v.leaf_index[g] = pos; v.leaf_slot[pos++] = g; }
     if (t == 1023) {
-        v.n_leaf[v.grp] = s_sum[1023];
+        v.nl[0] = s_sum[1023];
         atomicAdd(&v.counters[0], (unsigned long long)s_sum[1023]);
     }
 }
@@ -279,7 +307,7 @@ __global__ __launch_bounds__(1024) void k_compact(View v) {
 template <class G>
 __global__ void k_eval_hash(View v, uint64_t salt) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= v.n_leaf[v.grp]) return;
+    if (j >= v.nl[0]) return;
     j += v.lo;
     const int g = v.leaf_slot[j];
     const typename G::B m = board_load<G::W>(v.leaf_mine, g), t = board_load<G::W>(v.leaf_theirs, g);
@@ -291,18 +319,27 @@ __global__ void k_eval_hash(View v, uint64_t salt) {
 // ------------------------------------------------------------------------------------------------
 // expansion + backup of the evaluated leaves
 // ------------------------------------------------------------------------------------------------
-template <class G, int R>
-__global__ __launch_bounds__(64) void k_expand(View v) {
+// BY_SLOT = false: lane groups are mapped to the compacted leaves j (stand-alone k_expand); true: to the slots of
+// the group, a slot taking part if its last descent left a leaf awaiting expansion (fused expand + select kernel).
+template <class G, int R, bool BY_SLOT>
+__device__ __forceinline__ void expand_body(const View &v, double (*s_pa)[G::AP]) {
     constexpr int A = G::A, LPG = G::LPG, APL = G::APL, GPW = 64 / LPG;
     using WT = typename std::conditional<R == 0, float, double>::type;
     WT *wsum = R == 0 ? (WT *)v.wsum : (WT *)v.wsum_d;
-    __shared__ double s_pa[GPW][G::AP];             // staged priors for numpy's pairwise summation
     const int lane = threadIdx.x & (LPG - 1);
     const int grp = threadIdx.x / LPG;
     const int jl = blockIdx.x * GPW + grp;
-    const bool live = jl < v.n_leaf[v.grp];
-    const int j = v.lo + (live ? jl : 0);
-    const int g = v.leaf_slot[j];
+    bool live;
+    int j, g;
+    if constexpr (BY_SLOT) {
+        g = jl < v.n_act ? v.lo + jl : v.lo;
+        live = jl < v.n_act && v.pending[g] != 0;
+        j = live ? v.leaf_index[g] : v.lo;
+    } else {
+        live = jl < v.nl[0];
+        j = v.lo + (live ? jl : 0);
+        g = v.leaf_slot[j];
+    }
     const size_t base = (size_t)g * v.C;
     const typename G::B mine = board_load<G::W>(v.leaf_mine, g), theirs = board_load<G::W>(v.leaf_theirs, g);
 
@@ -340,38 +377,38 @@ __global__ __launch_bounds__(64) void k_expand(View v) {
         s = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
         for (int i = NB; i < A; ++i) s = s + s_pa[grp][i];
     }
-    if (!live) return;
-
     const int node = v.leaf_node[g];
     const int e = v.n_blk[g];                       // read by all lanes before lane 0 bumps it
     const int fc = 1 + e * A;
     const int L = v.path_len[g];
+    if (live) {
 #pragma unroll
-    for (int k = 0; k < APL; ++k) {
-        const int a = lane + k * LPG;
-        if (a >= A) continue;
-        const double pr = R != 1 ? pa[k] / s : (ok[k] ? pa[k] : -1.0);
-        double prior = pr;
-        // optional root exploration noise (off by default; not in the reference's search, listed in its
-        // src/deepmind_alphazero_pseudocode.py:285-290): prior*(1-eps) + noise*eps on the existing root children
-        if (L == (R == 1 ? 1 : 0) && v.root_noise != nullptr && child_exists<R>(pr))      // a root expansion
-            prior = pr * v.noise_keep + v.root_noise[(size_t)g * A + a] * v.noise_eps;
-        v.cnt[base + fc + a] = 0;                   // Node.expand :80-90
-        wsum[base + fc + a] = (WT)0;
-        v.prior[base + fc + a] = prior;
-        v.kids[base + fc + a] = 0;
-    }
-    // the value is the evaluator's float32 for the side to move at the leaf (rule set 1: value[state.player],
-    // a float32 widened by .tolist(), search.py:91); signs alternate upwards in both rule sets
-    const WT val = (WT)v.eval_v[j];
-    for (int k = lane; k < L; k += LPG) {           // backpropagate :214-223 / search.py:48-58
-        const int nd = v.path[(size_t)g * v.D + (L - 1 - k)];
-        const WT dv = (k & 1) ? -val : val;
-        wsum[base + nd] = wsum[base + nd] + dv;
-        v.cnt[base + nd] = v.cnt[base + nd] + 1;
+        for (int k = 0; k < APL; ++k) {
+            const int a = lane + k * LPG;
+            if (a >= A) continue;
+            const double pr = R != 1 ? pa[k] / s : (ok[k] ? pa[k] : -1.0);
+            double prior = pr;
+            // optional root exploration noise (off by default; not in the reference's search, listed in its
+            // src/deepmind_alphazero_pseudocode.py:285-290): prior*(1-eps) + noise*eps on the existing root children
+            if (L == (R == 1 ? 1 : 0) && v.root_noise != nullptr && child_exists<R>(pr))      // a root expansion
+                prior = pr * v.noise_keep + v.root_noise[(size_t)g * A + a] * v.noise_eps;
+            v.cnt[base + fc + a] = 0;                   // Node.expand :80-90
+            wsum[base + fc + a] = (WT)0;
+            v.prior[base + fc + a] = prior;
+            v.kids[base + fc + a] = 0;
+        }
+        // the value is the evaluator's float32 for the side to move at the leaf (rule set 1: value[state.player],
+        // a float32 widened by .tolist(), search.py:91); signs alternate upwards in both rule sets
+        const WT val = (WT)v.eval_v[j];
+        for (int k = lane; k < L; k += LPG) {           // backpropagate :214-223 / search.py:48-58
+            const int nd = v.path[(size_t)g * v.D + (L - 1 - k)];
+            const WT dv = (k & 1) ? -val : val;
+            wsum[base + nd] = wsum[base + nd] + dv;
+            v.cnt[base + nd] = v.cnt[base + nd] + 1;
+        }
     }
     __syncthreads();                                // all lanes have read n_blk
-    if (lane == 0) {
+    if (live && lane == 0) {
         v.kids[base + node] = fc;
         v.blk_parent[(size_t)g * v.E + e] = node;
         board_store<G::W>(v.st_mine, (size_t)g * v.E + e, mine);
@@ -381,11 +418,32 @@ __global__ __launch_bounds__(64) void k_expand(View v) {
     }
 }
 
+template <class G, int R>
+__global__ __launch_bounds__(64) void k_expand(View v) {
+    __shared__ double s_pa[64 / G::LPG][G::AP];     // staged priors for numpy's pairwise summation
+    expand_body<G, R, false>(v, s_pa);
+}
+
+// Expansion + backup of the leaves evaluated in round r-1 and the descent of round r in ONE launch: both are per-game
+// work on the same lane mapping, and games do not interact.  The leaves found here are appended to the group's OTHER
+// leaf counter (the one this kernel's expand phase read is still in use until the launch ends); the counter for the
+// round after next is zeroed.  Two launches per simulation round (this one + the evaluator) instead of four.
+template <class G, int R>
+__global__ __launch_bounds__(64) void k_expand_select(View v) {
+    __shared__ double s_pa[64 / G::LPG][G::AP];
+    extern __shared__ int s_path[];
+    if (blockIdx.x == 0 && threadIdx.x == 0) v.nl_other[0] = 0;      // the next fused launch appends there
+    expand_body<G, R, true>(v, s_pa);
+    __syncthreads();
+    __threadfence();                                // this game's new children are visible to its own descent
+    select_body<G, R, true>(v, s_path);
+}
+
 // compacted leaf positions as int8 cells, for the host evaluator
 template <class G>
 __global__ void k_leaf_cells(View v, int8_t *dst) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= v.n_leaf[v.grp]) return;
+    if (j >= v.nl[0]) return;
     const int g = v.leaf_slot[v.lo + j];
     board_to_cells<G>(board_load<G::W>(v.leaf_mine, g), board_load<G::W>(v.leaf_theirs, g), dst + (size_t)j * G::CELLS);
 }
@@ -697,6 +755,10 @@ void launch_eval_hash(int game, const View &v, uint64_t salt, hipStream_t s) {
 }
 void launch_expand(int game, const View &v, hipStream_t s) {
     RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expand<G, R>), dim3(games_grid<G>(v.n_act)), dim3(64), 0, s, v));
+}
+void launch_expand_select(int game, const View &v, hipStream_t s) {
+    RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expand_select<G, R>), dim3(games_grid<G>(v.n_act)), dim3(64),
+                                                    (size_t)(64 / G::LPG) * v.D * sizeof(int), s, v));
 }
 void launch_leaf_cells(int game, const View &v, int8_t *dst, hipStream_t s) {
     GAME_SWITCH(game, hipLaunchKernelGGL(k_leaf_cells<G>, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v, dst));
