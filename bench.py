@@ -61,9 +61,10 @@ def tree_report(st: dict, wall_s: float, n_actions: int = 7) -> dict:
             "rounds": int(st["rounds"]), "evals": int(st["evals"]), "terminal_leaves": int(st["terminal_leaves"]),
             "path_nodes": int(st["path_nodes"]), "sims_per_s": sims / wall_s, "evals_per_s": st["evals"] / wall_s,
             "mean_levels_selected": depth,
-            "roofline": {"bound": "hbm", "kernels": "k_select + k_compact + k_expand", "bytes_per_sim": bytes_per_sim,
+            "roofline": {"bound": "hbm", "kernels": "k_expand_select (expansion + backup of round r-1, descent of round r)",
+                         "bytes_per_sim": bytes_per_sim,
                          "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
-                         "traffic": (pmc_traffic("k_select") or 0) + (pmc_traffic("k_expand") or 0) or None}}
+                         "traffic": pmc_traffic("k_expand_select")}}
 
 
 def pmc_traffic(kernel: str):
