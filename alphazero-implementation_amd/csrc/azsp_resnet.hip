@@ -2,22 +2,26 @@
 // src/alphazero_simple/resnet.py:30-157 (stem, residual blocks, policy head, value head, masked
 // softmax, tanh) fused into ONE kernel, fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32.
 //
-// Mapping (one 256-thread workgroup = 4 wavefronts):
-//   * a workgroup owns TB boards = TB*cells rows of the implicit GEMM, padded to 256 rows
-//     (Connect-4: 6 boards x 42 cells = 252 rows).  Wave w owns rows [64w, 64w+64) = 2 MFMA row tiles
-//     and ALL output channels (NT = C/32 column tiles), so A fragments are reused NT times.
-//   * activations never leave the CU: the layer input lives in LDS as act[row][C+1] (row stride
-//     C+1 dwords -> conflict-free ds_read_b32 of one channel across 32 rows), the residual copy
-//     lives in registers in the MFMA C/D layout, and each conv writes its output back over the
-//     same LDS buffer after a barrier.  A 3x3 tap is an LDS row offset; taps that fall off the
-//     board read a shared all-zero row (validity mask precomputed per lane).
-//   * weights (BatchNorm folded on the host at upload) are pre-permuted into the B-fragment order
-//     [tap][k-step][lane][column tile] so that one coalesced 4*NT-byte load per lane feeds NT MFMAs;
-//     they stream from L2 (whole 64-channel tower = 1.2 MB).
-//   * heads: policy 1x1 conv and value 3x3 conv run on the same MFMA path (N padded to 32), their
-//     ReLU outputs go to LDS, the two Linear layers are per-board dot products reduced in a fixed
-//     order, then masked softmax / tanh.  Every board's result is independent of which tile /
-//     row it landed in (batch-invariant), so leaf order does not influence the search.
+// Mapping:
+//   * a workgroup owns TB boards = TB*cells rows of the implicit GEMM (Connect-4: 6 boards = 252 of 256 rows for large
+//     batches, 3 boards up to 768 boards, 1 board up to ~one workgroup per CU) and ALL output channels; its waves form
+//     an RW x CW grid of row groups x column groups.  The 64- and 128-channel Connect-4 kernels use RW = 2 and one wave
+//     per 32-channel column tile: a wave then owns 4 (or 2, or 1) row tiles x ONE column tile, and the weights of four
+//     k-steps arrive in one 16-byte load per lane (a vector-memory instruction in the MFMA stream costs matrix-pipe
+//     time); a tap's weights are loaded first, then one straight-line block of MFMAs runs per row tile.
+//   * activations never leave the CU: the layer input lives in LDS as act[row][C+1] (row stride C+1 dwords ->
+//     conflict-free ds_read_b32 of one channel across 32 rows), the residual copy lives in registers in the MFMA C/D
+//     layout, and each conv writes its output back over the same LDS buffer after a barrier.  A 3x3 tap is an LDS row
+//     offset; taps that fall off the board read a shared all-zero row (validity mask precomputed per lane).
+//   * 6-board workgroups take their GEMM rows in an order that groups the cells by the taps they lack (left / right
+//     column, top / bottom row, interior), so that a whole 32-row tile can skip its off-board taps: -16.7 % MFMAs,
+//     bit-identical results (build_row_order).
+//   * weights (BatchNorm folded on the host at upload) are pre-permuted into B-fragment order; they stream from L2
+//     (whole 64-channel tower = 1.2 MB).
+//   * heads: policy 1x1 conv on the same MFMA path, value 3x3 conv (3 channels) on v_mfma_f32_4x4x1_16B_f32; their
+//     ReLU outputs go to LDS, the two Linear layers are per-board dot products reduced in a fixed order, then masked
+//     softmax / tanh.  Every board's result is independent of which tile / row / variant it landed in
+//     (batch-invariant, tested bitwise), so leaf order does not influence the search.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
