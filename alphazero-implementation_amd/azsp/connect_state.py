@@ -46,13 +46,15 @@ class Action:
 
     def sample_next_state(self) -> "State":
         s = self.state
-        col = s.grid[:, self.column]
-        free = np.flatnonzero(col == -1)
-        if free.size == 0:
+        h = s.config.height
+        free = int(np.count_nonzero(s.grid[:, self.column] != -1))      # row 0 = bottom: lowest free row
+        if free >= h:
             raise ValueError(f"column {self.column} is full")
         grid = s.grid.copy()
-        grid[free[0], self.column] = s.player            # row 0 = bottom: lowest free row
-        return State(s.config, grid, 1 - s.player)
+        grid[free, self.column] = s.player
+        bits = list(s._bits)
+        bits[s.player] |= 1 << (self.column * (h + 1) + free)
+        return State(s.config, grid, 1 - s.player, _bits=tuple(bits))
 
     def to_json(self) -> dict:
         return {"state": self.state.to_json(), "column": self.column}
@@ -72,11 +74,13 @@ class Action:
 
 
 class State:
-    def __init__(self, config: Config, grid, player: int):
+    def __init__(self, config: Config, grid, player: int, _bits=None):
         self.config = config
         self.grid = np.asarray(grid, dtype=np.int8).reshape(config.height, config.width)
         self.player = int(player)
-        winner = _winner(self.grid, config.count)
+        # one bit set per player: cell (row r from the bottom, column c) -> bit c * (height + 1) + r
+        self._bits = _bits if _bits is not None else _to_bits(self.grid)
+        winner = _winner(self._bits, config.height, config.count)
         full = not (self.grid[config.height - 1] == -1).any()
         self.has_ended = winner is not None or full
         self.reward = np.zeros(config.num_players, dtype=np.float32)
@@ -111,19 +115,23 @@ class State:
         return "State(player=%d)\n%s" % (self.player, "\n".join(rows))
 
 
-def _winner(grid: np.ndarray, k: int):
-    h, w = grid.shape
+def _to_bits(grid: np.ndarray) -> tuple:
+    h = grid.shape[0]
+    out = []
     for who in (0, 1):
-        m = grid == who
-        for dr, dc in ((0, 1), (1, 0), (1, 1), (1, -1)):
-            run = np.ones_like(m)
-            for i in range(k):
-                sh = np.zeros_like(m)
-                r0, r1 = max(0, -i * dr), min(h, h - i * dr)
-                c0, c1 = max(0, -i * dc), min(w, w - i * dc)
-                if r0 < r1 and c0 < c1:
-                    sh[r0:r1, c0:c1] = m[r0 + i * dr:r1 + i * dr, c0 + i * dc:c1 + i * dc]
-                run &= sh
-            if run.any():
+        r, c = np.nonzero(grid == who)
+        out.append(int(sum(1 << (int(cc) * (h + 1) + int(rr)) for rr, cc in zip(r, c))))
+    return tuple(out)
+
+
+def _winner(bits: tuple, h: int, k: int):
+    """k in a row on bit sets with one spare bit per column: vertical 1, horizontal h + 1, diagonals h and h + 2."""
+    for who in (0, 1):
+        m = bits[who]
+        for step in (1, h + 1, h, h + 2):
+            run = m
+            for i in range(1, k):
+                run &= m >> (i * step)
+            if run:
                 return who
     return None
