@@ -61,9 +61,10 @@ def export_records(gen, device: torch.device | None = None) -> torch.Tensor:
     if eng is None or st is None:
         raise RuntimeError("export_records needs a finished generate_episodes run")
     n_eps = eng.n_slots
-    device = device or torch.device("cuda", torch.cuda.current_device())
+    device = eng.torch_device(device)          # the export kernel writes on the engine's own GPU
     cap = n_eps * eng.max_plies
     buf = torch.empty((cap, eng.record_bytes), dtype=torch.uint8, device=device)
+    eng.sync_torch_stream()
     n = eng.export_records_device(0, n_eps, buf.data_ptr(), cap)
     return buf[:n]
 

@@ -39,6 +39,7 @@ class Engine:
         self.cells = self.rows * self.cols
         self.board_shape = (self.rows, self.cols) if self.rows > 1 else (self.cols,)
         self.n_slots, self.n_sims = int(n_slots), int(n_sims)
+        self.device = int(device)
         self.res_blocks, self.channels = int(res_blocks), int(channels)
         cfg = L.Config(C.sizeof(L.Config), self.game_id, self.n_slots, self.n_sims, int(device), self.res_blocks,
                        self.channels, (L.FLAG_TIMING if timing else 0) | (L.FLAG_F16_SPLIT if f16_split else 0) | (L.FLAG_TREE_REUSE if tree_reuse else 0), int(hash_salt) & (2**64 - 1), int(n_groups), int(arena_episodes),
@@ -227,6 +228,23 @@ class Engine:
         if got < 0:
             L.check(int(got))
         return int(got)
+
+    def torch_device(self, requested=None):
+        """torch.device of this engine's GPU: where the azsp_export_*_device destinations must live (the engine's kernel
+        writes through raw pointers on its own device and stream).  A different `requested` device is refused."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        if requested is not None:
+            req = torch.device(requested)
+            if req.type != "cuda" or (req.index is not None and req.index != self.device):
+                raise ValueError(f"the engine lives on {dev}; it cannot export into memory on {req}")
+        return dev
+
+    def sync_torch_stream(self) -> None:
+        """Wait for PyTorch's current stream on the engine's device: a block torch.empty hands out may still have work
+        pending there, and the engine's private stream does not order itself behind it."""
+        import torch
+        torch.cuda.current_stream(self.device).synchronize()
 
     @property
     def record_bytes(self) -> int:

@@ -298,6 +298,12 @@ class AlphaZeroSearch:
             return
         if any(n.state.has_ended for n in current_nodes):
             raise ValueError("cannot search from a finished game")
+        if any(n.visit_count or n.children for n in current_nodes):
+            # search.py:66-91 would descend the node's existing tree and add num_simulations more visits to it; the
+            # device search always starts from an unexpanded root, so a second run on the same Node is refused rather
+            # than silently restarted (improved_policy = n / (N - 1) would no longer sum to 1)
+            raise ValueError("run_simulations needs fresh nodes (visit_count == 0, no children): the device search "
+                             "does not continue an existing host-side tree; wrap the state in a new Node")
         parity = {(int(n.state.player) - int(np.count_nonzero(np.asarray(n.state.grid) != -1))) % 2 for n in current_nodes}
         if len(parity) != 1:
             raise ValueError("states of one batch must agree on which player moves at an even number of pieces")
@@ -306,8 +312,8 @@ class AlphaZeroSearch:
         out = eng.run_batch(np.stack([canonical_cells(n.state) for n in current_nodes]))
         val = eng.root_values(len(current_nodes))
         for i, node in enumerate(current_nodes):
-            node.visit_count += int(val["root_n"][i])
-            node.value_sum += float(val["root_w"][i])
+            node.visit_count = int(val["root_n"][i])
+            node.value_sum = float(val["root_w"][i])
             node.children = {}
             for a in node.state.actions:
                 child = Node(None, node, float(out["prior"][i, a.column]))
@@ -416,11 +422,12 @@ def generate_dataset(gen: EpisodeGenerator, initial_state=None, device=None):
             break
         eng.search()
     gen.last_stats = eng.stats()
-    device = device or torch.device("cuda", torch.cuda.current_device())
+    device = eng.torch_device(device)          # the export kernel writes on the engine's own GPU
     s = int(res.samples_total)
     planes = torch.empty((s, 3, eng.rows, eng.cols), dtype=torch.float32, device=device)
     pol = torch.empty((s, eng.n_actions), dtype=torch.float32, device=device)
     z = torch.empty((s,), dtype=torch.float32, device=device)
+    eng.sync_torch_stream()
     got = eng.export_dataset_device(0, n, planes.data_ptr(), pol.data_ptr(), z.data_ptr(), s)
     assert got == s
     # the engine's z is the outcome for the sample's side to move; gen-1 stores the vector over absolute players

@@ -127,7 +127,18 @@ class ResNet(BaseModel):
 
     # ---- inference on the HIP engine ------------------------------------------------------------
     def _fingerprint(self):
-        return tuple(int(t._version) for t in list(self.parameters()) + list(self.buffers()))
+        """What decides whether the device copy of the weights is current: storage address and in-place version of
+        every tensor.  `_version` does not see writes through `.data` (p.data.copy_(), m.weight.data.normal_()) or
+        `set_()`: after such an update call `invalidate_device_weights()` (load_state_dict does it by itself)."""
+        return tuple((int(t.data_ptr()), int(t._version)) for t in list(self.parameters()) + list(self.buffers()))
+
+    def invalidate_device_weights(self) -> None:
+        """Force the next predict() to re-upload the weights to the device engine."""
+        self._azsp_fingerprint = None
+
+    def load_state_dict(self, *args, **kwargs):
+        self._azsp_fingerprint = None
+        return super().load_state_dict(*args, **kwargs)
 
     def predict(self, boards: list[np.ndarray]) -> tuple[list[np.ndarray], list[float]]:
         """boards -> (list of float32[A] move probabilities, list of float32 values); masked softmax

@@ -37,12 +37,13 @@ def generate_dataset(gen, model, device: torch.device | None = None) -> TensorDa
             break
         eng.search()
     gen.last_stats = eng.stats()
-    device = device or torch.device("cuda", torch.cuda.current_device())
+    device = eng.torch_device(device)          # the export kernel writes on the engine's own GPU
     s = int(res.samples_total)
     rows, cols = (eng.rows, eng.cols)
     planes = torch.empty((s, 3, rows, cols), dtype=torch.float32, device=device)
     pol = torch.empty((s, eng.n_actions), dtype=torch.float32, device=device)
     val = torch.empty((s,), dtype=torch.float32, device=device)
+    eng.sync_torch_stream()
     got = eng.export_dataset_device(0, n, planes.data_ptr(), pol.data_ptr(), val.data_ptr(), s)
     assert got == s
     return TensorDataset(planes, pol, val)

@@ -35,6 +35,24 @@ static int fail(int code, const char *fmt, ...) {
             return fail(AZSP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+// Every entry point works on the engine's own device and leaves the calling thread's current device as it found it
+// (a training loop next to the generator keeps its torch.cuda.current_device()).
+struct DeviceScope {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = prev == dev || hipSetDevice(dev) == hipSuccess;
+        if (prev == dev) prev = -1;                // nothing to restore
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define ON_DEVICE(dev)                                                                    \
+    DeviceScope _dev_scope(dev);                                                          \
+    if (!_dev_scope.ok) return fail(AZSP_ERR_HIP, "hipSetDevice(%d) failed", (int)(dev))
+
 struct GameInfo { int rows, cols, A, cells, max_plies, W, AP; };
 static bool game_info(int game, GameInfo &gi) {
     switch (game) {
@@ -183,7 +201,7 @@ static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
             if (!e->net || !e->net_loaded) return fail(AZSP_ERR_STATE, "ResNet evaluator selected but no weights loaded (azsp_load_resnet)");
             EventPair *p = ev_begin(e, EV_INFER, st);
             resnet_forward(e->net, game, v.leaf_mine, v.leaf_theirs, v.leaf_slot + v.lo, v.nl, v.n_act,
-                           v.eval_p + (size_t)v.lo * PSTRIDE, v.eval_v + v.lo, st);   // ResNet: Connect-4 only, AP == PSTRIDE
+                           v.eval_p + (size_t)v.lo * e->gi.AP, v.eval_v + v.lo, st);   // rows of the game's padded width AP
             ev_end(p, st);
             e->stats.infer_launches++;
             return 0;
@@ -363,7 +381,7 @@ size_t azsp_resnet_blob_floats(int32_t game, int32_t res_blocks, int32_t channel
 
 void azsp_destroy(azsp_engine *e) {
     if (!e) return;
-    (void)hipSetDevice(e->cfg.device);
+    DeviceScope _dev_scope(e->cfg.device);
     for (int k = 0; k < MAX_GROUPS; ++k) if (e->gstream[k]) (void)hipStreamSynchronize(e->gstream[k]);
     for (auto &p : e->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -399,7 +417,7 @@ static int upload_exploration_tables(azsp_engine *e) {
 static int create_impl(azsp_engine *e) {
     const azsp_config &c = e->cfg;
     const GameInfo &gi = e->gi;
-    HIP_TRY(hipSetDevice(c.device));
+    ON_DEVICE(c.device);
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->gstream[0] = e->stream;
     e->n_groups = c.n_groups > 0 ? (c.n_groups > MAX_GROUPS ? MAX_GROUPS : c.n_groups) : (c.n_slots >= 3072 ? 3 : (c.n_slots >= 1024 ? 2 : 1));
@@ -539,7 +557,7 @@ int azsp_set_evaluator(azsp_engine *e, int32_t kind, azsp_predict_fn fn, void *u
 int azsp_load_resnet(azsp_engine *e, const float *blob, size_t n_floats) {
     if (!e || !blob) return fail(AZSP_ERR_ARG, "null argument");
     if (!e->net) return fail(AZSP_ERR_STATE, "engine was created without a ResNet geometry");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     const size_t want = resnet_blob_floats(e->cfg.game, e->cfg.res_blocks, e->cfg.channels);
     if (n_floats != want) return fail(AZSP_ERR_ARG, "weight blob has %zu floats, expected %zu", n_floats, want);
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -551,7 +569,7 @@ int azsp_load_resnet(azsp_engine *e, const float *blob, size_t n_floats) {
 
 int azsp_sync(azsp_engine *e) {
     if (!e) return fail(AZSP_ERR_ARG, "null engine");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     return sync_stream(e);
 }
 
@@ -568,7 +586,7 @@ static int upload_boards(azsp_engine *e, const int8_t *boards, int n) {
 
 int azsp_predict(azsp_engine *e, const int8_t *boards, int32_t n, float *p_out, float *v_out) {
     if (!e || !boards || n < 0) return fail(AZSP_ERR_ARG, "bad argument");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     const int N = e->cfg.n_slots, A = e->gi.A, AP = e->gi.AP;
     for (int lo = 0; lo < n; lo += N) {
         const int m = (n - lo < N) ? n - lo : N;
@@ -612,7 +630,7 @@ int azsp_run_batch(azsp_engine *e, const int8_t *boards, int32_t n, int32_t *cou
                    float *root_w, int32_t *root_n) {
     if (!e || !boards || n <= 0) return fail(AZSP_ERR_ARG, "bad argument");
     if (n > e->cfg.n_slots) return fail(AZSP_ERR_ARG, "n %d exceeds n_slots %d", n, e->cfg.n_slots);
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     const int A = e->gi.A;
     int rc = upload_boards(e, boards, n);
     if (rc) return rc;
@@ -635,16 +653,20 @@ int azsp_run_batch(azsp_engine *e, const int8_t *boards, int32_t n, int32_t *cou
 
 int azsp_reset(azsp_engine *e) {
     if (!e) return fail(AZSP_ERR_ARG, "null engine");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     e->v.n_act = e->cfg.n_slots;
     launch_reset_slots(e->cfg.game, e->v, e->stream);
     e->searched = false;
-    return sync_stream(e);
+    e->play_open = false;
+    int rc = sync_stream(e);
+    if (rc) return rc;
+    memset(e->h_res, 0, sizeof(PlyResultDev));      // the fetch/export calls check their ranges against this mirror
+    return 0;
 }
 
 int azsp_search(azsp_engine *e) {
     if (!e) return fail(AZSP_ERR_ARG, "null engine");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     return search(e, e->cfg.n_slots);
 }
 
@@ -654,7 +676,7 @@ int azsp_set_search_options(azsp_engine *e, const azsp_search_options *o) {
     if (o->noise_eps < 0.0 || o->noise_eps > 1.0) return fail(AZSP_ERR_ARG, "noise_eps out of [0,1]");
     if (!(o->c_init == o->c_init) || !(o->c_base == o->c_base) || o->c_base < 0.0)
         return fail(AZSP_ERR_ARG, "c_init / c_base must be numbers, c_base >= 0");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     HIP_TRY(hipStreamSynchronize(e->stream));      // no search may be reading the tables
     e->v.sampling_plies = o->sampling_plies;
     e->v.noise_eps = o->noise_eps;
@@ -666,7 +688,7 @@ int azsp_set_search_options(azsp_engine *e, const azsp_search_options *o) {
 
 int azsp_search_with_noise(azsp_engine *e, const double *noise) {
     if (!e || !noise) return fail(AZSP_ERR_ARG, "null argument");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     HIP_TRY(hipMemcpyAsync(e->d_noise, noise, (size_t)e->cfg.n_slots * e->gi.A * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));            // the caller's buffer may be pageable
     e->v.root_noise = e->d_noise;
@@ -678,7 +700,7 @@ int azsp_search_with_noise(azsp_engine *e, const double *noise) {
 int azsp_root_counts(azsp_engine *e, int32_t *counts) {
     if (!e || !counts) return fail(AZSP_ERR_ARG, "null argument");
     if (!e->searched) return fail(AZSP_ERR_STATE, "azsp_root_counts before azsp_search");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     const int N = e->cfg.n_slots, A = e->gi.A;
     int32_t *d_counts = e->d_st_counts;
     launch_root_stats(e->cfg.game, e->v, d_counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, e->stream);
@@ -688,7 +710,7 @@ int azsp_root_counts(azsp_engine *e, int32_t *counts) {
 
 int azsp_root_values(azsp_engine *e, int32_t n, double *child_w, double *root_w, int32_t *root_n) {
     if (!e || n <= 0 || n > e->cfg.n_slots) return fail(AZSP_ERR_ARG, "bad argument");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     const int A = e->gi.A;
     View v = e->v;
     v.n_act = n;
@@ -716,7 +738,7 @@ int azsp_set_initial_board(azsp_engine *e, const int8_t *cells) {
 
 int azsp_fetch_moves(azsp_engine *e, int64_t first, int64_t n, int32_t *moves, int64_t sample_cap) {
     if (!e || first < 0 || n < 0 || !moves) return fail(AZSP_ERR_ARG, "bad argument");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     if (first + n > e->h_res->episodes_total) return fail(AZSP_ERR_ARG, "episodes not emitted yet");
     if (n == 0) return 0;
     int64_t off[2];
@@ -737,7 +759,7 @@ int azsp_play_begin(azsp_engine *e, const double *uniforms, int32_t *n_done) {
         return fail(AZSP_ERR_STATE, "n_sims = 0: the visit distribution is 0/0 (the reference raises in np.random.choice)");
     if (e->cfg.search_rules == AZSP_RULES_GEN1 && e->cfg.n_sims < 2)
         return fail(AZSP_ERR_STATE, "n_sims = 1 under AZSP_RULES_GEN1: pi = n / (N - 1) divides by zero (node.py:24-29 raises)");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     const int N = e->cfg.n_slots;
     HIP_TRY(hipMemcpyAsync(e->d_uniforms, uniforms, (size_t)N * sizeof(double), hipMemcpyHostToDevice, e->stream));
     EventPair *p = ev_begin(e, EV_PLAY, e->stream);
@@ -757,7 +779,7 @@ int azsp_play_begin(azsp_engine *e, const double *uniforms, int32_t *n_done) {
 int azsp_play_commit(azsp_engine *e, int64_t allow, azsp_ply_result *out) {
     if (!e || !out) return fail(AZSP_ERR_ARG, "null argument");
     if (!e->play_open) return fail(AZSP_ERR_STATE, "azsp_play_commit without azsp_play_begin");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     EventPair *p = ev_begin(e, EV_PLAY, e->stream);
     launch_emit(e->cfg.game, e->v, e->h_res, allow < 0 ? -1ll : (long long)allow, e->stream);
     ev_end(p, e->stream);
@@ -787,7 +809,7 @@ int azsp_play(azsp_engine *e, const double *uniforms, azsp_ply_result *out) {
 int azsp_fetch_episodes(azsp_engine *e, int64_t first, int64_t n, int64_t *ep_offset, int32_t *ep_slot, int32_t *ep_ply,
                         int8_t *states, double *policies, int32_t *values, int64_t sample_cap) {
     if (!e || first < 0 || n < 0) return fail(AZSP_ERR_ARG, "bad argument");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     // No stream synchronisation: emitted episodes were complete when azsp_play returned, and the arena
     // is append-only until the next azsp_play, so a search already enqueued may run during the copy.
     if (first + n > e->h_res->episodes_total) return fail(AZSP_ERR_ARG, "episodes [%lld,%lld) not emitted yet (have %lld)", (long long)first, (long long)(first + n), (long long)e->h_res->episodes_total);
@@ -808,7 +830,7 @@ int azsp_fetch_episodes(azsp_engine *e, int64_t first, int64_t n, int64_t *ep_of
 
 int64_t azsp_export_records_device(azsp_engine *e, int64_t first, int64_t n, void *dev_dst, int64_t cap_records) {
     if (!e || first < 0 || n < 0 || !dev_dst) return fail(AZSP_ERR_ARG, "bad argument");
-    if (hipSetDevice(e->cfg.device) != hipSuccess) return fail(AZSP_ERR_HIP, "hipSetDevice failed");
+    ON_DEVICE(e->cfg.device);
     if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(AZSP_ERR_HIP, "stream sync failed");
     if (first + n > e->h_res->episodes_total) return fail(AZSP_ERR_ARG, "episodes not emitted yet");
     if (n == 0) return 0;
@@ -826,7 +848,7 @@ int64_t azsp_export_records_device(azsp_engine *e, int64_t first, int64_t n, voi
 int64_t azsp_export_dataset_device(azsp_engine *e, int64_t first, int64_t n, float *planes, float *policies, float *values,
                                    int64_t cap_samples) {
     if (!e || first < 0 || n < 0 || !planes || !policies || !values) return fail(AZSP_ERR_ARG, "bad argument");
-    if (hipSetDevice(e->cfg.device) != hipSuccess) return fail(AZSP_ERR_HIP, "hipSetDevice failed");
+    ON_DEVICE(e->cfg.device);
     if (first + n > e->h_res->episodes_total) return fail(AZSP_ERR_ARG, "episodes not emitted yet");
     if (n == 0) return 0;
     int64_t off[2];
@@ -843,7 +865,7 @@ int64_t azsp_export_dataset_device(azsp_engine *e, int64_t first, int64_t n, flo
 
 int azsp_get_stats(azsp_engine *e, azsp_stats *out) {
     if (!e || !out) return fail(AZSP_ERR_ARG, "null argument");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     int rc = sync_stream(e);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(e->h_counters, e->v.counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -859,7 +881,7 @@ int azsp_get_stats(azsp_engine *e, azsp_stats *out) {
 
 int azsp_reset_stats(azsp_engine *e) {
     if (!e) return fail(AZSP_ERR_ARG, "null engine");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     int rc = sync_stream(e);
     if (rc) return rc;
     HIP_TRY(hipMemset(e->v.counters, 0, 8 * sizeof(unsigned long long)));

@@ -7,7 +7,6 @@
 
 namespace azsp {
 
-constexpr int PSTRIDE = 8;   // floats per policy row written by the ResNet kernels (= Connect4::AP)
 constexpr int MAX_GROUPS = 8; // slot groups searched concurrently on separate HIP streams
 
 // Device-resident state of one engine.  Structure-of-arrays; every per-node array is [slot][C].

@@ -392,7 +392,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
 #pragma unroll
         for (int a = 0; a < A; ++a) { ex[a] = ((legal >> a) & 1u) ? expf(logits[tid * 8 + a] - mx) : 0.0f; den += ex[a]; }
 #pragma unroll
-        for (int a = 0; a < PSTRIDE; ++a) out_p[(size_t)j * PSTRIDE + a] = a < A ? ex[a < A ? a : 0] / den : 0.0f;
+        for (int a = 0; a < Connect4::AP; ++a) out_p[(size_t)j * Connect4::AP + a] = a < A ? ex[a < A ? a : 0] / den : 0.0f;
         out_v[j] = tanhf(logits[tid * 8 + 7]);
     }
     STAMP16(55);

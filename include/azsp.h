@@ -9,7 +9,11 @@
  *     the call returns except the evaluator callback and its user pointer.
  *   - return value: 0 = ok, < 0 = error code; azsp_last_error() gives the message of the last
  *     failing call on the calling thread.  Nothing throws across the ABI.
- *   - one engine = one HIP device + one private non-blocking HIP stream.  Calls on one engine must
+ *   - one engine = one HIP device + one private non-blocking HIP stream.  Every entry point switches the
+ *     calling thread to the engine's device and restores the thread's previous current device before it
+ *     returns.  Device pointers handed to the azsp_export_*_device calls must live on the engine's device;
+ *     the engine's stream does not wait for work the caller has pending on other streams (synchronise those
+ *     first), and the call returns after its own stream has drained.  Calls on one engine must
  *     be serialised by the caller; different engines may be used from different threads (the
  *     reference runs generation on a daemon thread next to training:
  *     src/alphazero_less_simple/core/training/datamodule.py:19-47,111-117).
@@ -154,7 +158,9 @@ int  azsp_load_resnet(azsp_engine *e, const float *blob, size_t n_floats);
 size_t azsp_resnet_blob_floats(int32_t game, int32_t res_blocks, int32_t channels);
 int  azsp_set_evaluator(azsp_engine *e, int32_t kind, azsp_predict_fn fn, void *user);
 
-/* BaseModel.predict (resnet.py:130-157) with the engine's current evaluator. */
+/* BaseModel.predict (resnet.py:130-157) with the engine's current evaluator.  Uses the slots as staging: like
+ * azsp_run_batch it overwrites the live games of a generation run in progress (call azsp_reset before the next
+ * azsp_search); episodes already emitted stay fetchable. */
 int  azsp_predict(azsp_engine *e, const int8_t *boards, int32_t n, float *p_out, float *v_out);
 
 /* ---- search facade: MCTS.run_batch (src/alphazero_simple/monte_carlo_tree_search.py:111-171) --- */
@@ -172,7 +178,8 @@ int  azsp_root_values(azsp_engine *e, int32_t n, double *child_w, double *root_w
 
 /* ---- episode generation: EpisodeGenerator.generate_episodes
  *      (src/alphazero_less_simple/core/training/episode_generator.py:23-87) --------------------- */
-int  azsp_reset(azsp_engine *e);                       /* :25-29  fresh games in every slot          */
+int  azsp_reset(azsp_engine *e);                       /* :25-29  fresh games in every slot; the episode arena is
+                                                          empty again (fetch/export of earlier episodes fail)      */
 /* The position every game starts from (canonical cells; NULL = empty board, the default).  Stands behind
  * generate_episodes(initial_state) of src/alphazero_implementation/core/training/episode_generator.py:35-45.
  * Takes effect at the next azsp_reset and at every slot restart. */

@@ -54,7 +54,9 @@ def random_midgame_boards(rules, rng, n, max_plies):
 
 
 def check_episode_invariants(rules, states, policies, values, sims):
-    """Size-independent properties of one emitted episode (used at BASELINE's full sizes)."""
+    """Size-independent properties of one emitted episode (used at BASELINE's full sizes).  Works for any game whose
+    action index is the column (Connect-4) or the flat cell index (Gomoku 9x9: action = row * 9 + column)."""
+    flat_actions = rules.action_size == int(np.prod(np.asarray(states[0]).shape))
     L = len(states)
     assert 1 <= L
     counts = np.rint(policies * sims).astype(np.int64)
@@ -65,7 +67,8 @@ def check_episode_invariants(rules, states, policies, values, sims):
         # next canonical state = flip(previous + one stone of the mover on a column with pi > 0)
         diff = (-states[k + 1]) - states[k]
         assert np.count_nonzero(diff) == 1 and diff.sum() == 1
-        col = int(np.argwhere(diff != 0)[0][-1])
+        where = np.argwhere(diff != 0)[0]
+        col = int(where[0] * diff.shape[1] + where[1]) if flat_actions else int(where[-1])
         assert policies[k][col] > 0
     # the final position must be non-terminal, and some move with pi > 0 ends the game with z
     last = states[-1]
@@ -104,3 +107,24 @@ class FixedPriorModel:
 
     def predict(self, boards):
         return [self.p.copy() for _ in boards], [self.v for _ in boards]
+
+
+def min_puct_margin(rules, predict, sims, state):
+    """Smallest gap between the best and the second-best PUCT score over every selection step of one search from
+    `state` (oracle search fed by `predict`): how close the search came to a tie.  Used to qualify a divergence between
+    a transcript recorded with torch-CPU network floats and a run with the device network's floats."""
+    best = {"gap": float("inf")}
+    orig = oz.ONode.best_child
+
+    def spy(self, c_of=None):
+        scores = sorted((float(oz.puct(self, c, c_of)) for c in self.kids.values()), reverse=True)
+        if len(scores) > 1:
+            best["gap"] = min(best["gap"], scores[0] - scores[1])
+        return orig(self, c_of)
+
+    oz.ONode.best_child = spy
+    try:
+        oz.run_batch(rules, predict, sims, [np.asarray(state)], [1])
+    finally:
+        oz.ONode.best_child = orig
+    return best["gap"]

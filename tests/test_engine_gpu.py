@@ -142,6 +142,32 @@ def test_generate_matches_c_oracle_at_larger_sizes(azsp, n, sims, seed, salt, gr
 
 
 # ------------------------------------------------------------------------------------ network
+# Absolute bounds on |p - p_ref| and |v - v_ref| against a float32 torch-CPU forward of the same weights.  north_star
+# asks for 1e-6 (NORTH_STAR_TOL): that is asserted for BASELINE's three networks with the random weights BASELINE
+# names (default initialisation), test_baseline_networks_within_north_star_tolerance.  The kernels are otherwise held
+# to what they measure (printed as [net-error] lines; round-2 run: <= 3.9e-7 everywhere but one case): NET_TOL for the
+# reference's own vectors and every geometry the kernels are instantiated for, NET_TOL_WIDE only for the 8 x 128 stress
+# net (randomised BatchNorm statistics let activations grow through 16 layers: 1.0e-6 on v, against 1.7e-7 for torch's
+# own float32 forward relative to float64 -- the kernel sums each output's K = 9 * C products in one float32 chain).
+NET_TOL = 5e-7
+NET_TOL_WIDE = 2e-6
+NORTH_STAR_TOL = 1e-6
+
+
+def _torch_reference(net, rules, boards, double=False):
+    """Masked softmax / tanh of the module's own PyTorch forward on the CPU (float32, or float64 as a yardstick)."""
+    import copy
+    import torch
+    m = copy.deepcopy(net).double() if double else net
+    with torch.no_grad():
+        x = net._states_to_tensor(boards)
+        logits, vl = m.forward(x.double() if double else x)
+        mask = torch.tensor(np.array([rules.valid_moves(b) for b in boards]))
+        pt = torch.softmax(logits.masked_fill(mask == 0, float("-inf")), dim=1).numpy()
+        vt = torch.tanh(vl).numpy()
+    return pt, vt, mask.numpy()
+
+
 def _golden_net(tag):
     z = np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "resnet_forward.npz"))
     sd = {k[len(tag) + 4:]: z[k] for k in z.files if k.startswith(f"{tag}_sd/")}
@@ -152,7 +178,8 @@ def _golden_net(tag):
 @pytest.mark.parametrize("tag", ["s", "m"])
 def test_resnet_forward_matches_reference_vectors(azsp, tag, f16):
     """Fused MFMA tower vs ResNet.predict of the reference on torch-CPU.  fp32 everywhere, different
-    summation order and BN folding -> tolerance 1e-5 absolute on probabilities and tanh values."""
+    summation order and BN folding -> tolerance NET_TOL (5e-7, below north_star's 1e-6) absolute on probabilities
+    and tanh values; the measured error is printed."""
     from azsp.weights import resnet_blob
     z, sd = _golden_net(tag)
     blob, blocks, ch = resnet_blob({k: v for k, v in sd.items() if "num_batches_tracked" not in k})
@@ -164,8 +191,9 @@ def test_resnet_forward_matches_reference_vectors(azsp, tag, f16):
         p2, v2 = e.predict(boards[::-1].copy())            # batch-invariance: other order, other tiles
     assert np.array_equal(p2[::-1], p) and np.array_equal(v2[::-1], v)
     assert np.all(p[z[f"{tag}_p"] == 0] == 0)               # exact zeros on illegal columns
-    assert np.max(np.abs(p - z[f"{tag}_p"])) < 1e-5
-    assert np.max(np.abs(v - z[f"{tag}_v"])) < 1e-5
+    err_p, err_v = np.max(np.abs(p - z[f"{tag}_p"])), np.max(np.abs(v - z[f"{tag}_v"]))
+    print(f"[net-error] reference vectors {tag} ({blocks}x{ch}) f16x2={f16}: max |dp| = {err_p:.2e}, max |dv| = {err_v:.2e}")
+    assert err_p < NET_TOL and err_v < NET_TOL
     assert np.all(np.abs(p.sum(axis=1) - 1) < 1e-6)
 
 
@@ -204,7 +232,8 @@ def test_resnet_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp, f16):
                                        (2, 192), (2, 256)])
 def test_resnet_model_predict_uses_device_kernel(azsp, blocks, ch, f16, monkeypatch):
     """azsp.ResNet.predict (HIP kernel) vs the same module's PyTorch forward on the CPU, for every
-    channel-tile count the kernel is instantiated for (C padded to 32/64/128).  Tolerance 1e-5."""
+    channel-tile count the kernel is instantiated for (C padded to 32/64/128).  Tolerance NET_TOL for the BASELINE
+    geometries, NET_TOL_WIDE otherwise; also printed: both against a float64 forward."""
     import torch
     if f16 and ch > 128:
         pytest.skip("the split-fp16 kernel covers up to 128 channels")
@@ -222,20 +251,43 @@ def test_resnet_model_predict_uses_device_kernel(azsp, blocks, ch, f16, monkeypa
     rules = oz.C4Rules()
     boards = random_midgame_boards(rules, np.random.RandomState(2), 20, 40)
     p, v = net.predict(boards)
-    with torch.no_grad():
-        logits, vl = net.forward(net._states_to_tensor(boards))
-        mask = torch.tensor([rules.valid_moves(b) for b in boards])
-        pt = torch.softmax(logits.masked_fill(mask == 0, float("-inf")), dim=1).numpy()
-        vt = torch.tanh(vl).numpy()
+    pt, vt, _ = _torch_reference(net, rules, boards)
+    p64, v64, _ = _torch_reference(net, rules, boards, double=True)
     err_p, err_v = np.max(np.abs(np.stack(p) - pt)), np.max(np.abs(np.array(v) - vt))
-    print(f"blocks={blocks} ch={ch} f16x2={f16}: max |dp| = {err_p:.2e}, max |dv| = {err_v:.2e}")
-    assert err_p < 1e-5 and err_v < 1e-5
+    print(f"[net-error] connect4 {blocks}x{ch} f16x2={f16}: max |dp| = {err_p:.2e}, max |dv| = {err_v:.2e} vs torch f32; "
+          f"vs float64: kernel {np.max(np.abs(np.stack(p) - p64)):.2e} / {np.max(np.abs(np.array(v) - v64)):.2e}, "
+          f"torch f32 {np.max(np.abs(pt - p64)):.2e} / {np.max(np.abs(vt - v64)):.2e}")
+    tol = NET_TOL_WIDE if (blocks, ch) == (8, 128) else NET_TOL     # the deep stress net, see the note on the bounds
+    assert err_p < tol and err_v < tol
     clone = net.get_inference_clone()
     assert clone._azsp_engine is None and net._azsp_engine is not None
     with torch.no_grad():                          # weights change -> next predict re-uploads
         net.policy_head[4].bias[0] += 1.0         # (a uniform shift would leave the softmax unchanged)
     p2, _ = net.predict(boards)
     assert not np.allclose(np.stack(p2), np.stack(p))
+
+
+@pytest.mark.parametrize("game,blocks,ch", [("connect4", 4, 64), ("connect4", 8, 128), ("gomoku9", 10, 256)])
+def test_baseline_networks_within_north_star_tolerance(azsp, game, blocks, ch):
+    """BASELINE.json's three networks with the weights its configs name ("random weights" = PyTorch's default
+    initialisation, torch.manual_seed(0) as in bench.py): p and tanh(v) of the device kernel (exact fp32 and split
+    fp16 where that kernel exists) within north_star's 1e-6 of the module's float32 PyTorch forward."""
+    import torch
+    torch.manual_seed(0)
+    shape, A, rules = ((6, 7), 7, oz.C4Rules()) if game == "connect4" else ((9, 9), 81, oz.G9Rules())
+    net = azsp.ResNet(shape, A, blocks, ch).eval()
+    boards = random_midgame_boards(rules, np.random.RandomState(12), 48, 40)
+    pt, vt, mask = _torch_reference(net, rules, boards)
+    from azsp.weights import resnet_blob
+    blob = resnet_blob(net)[0]
+    for f16 in ((False, True) if game == "connect4" else (False,)):
+        with _engine(azsp, game, 64, 1, res_blocks=blocks, channels=ch, f16_split=f16) as e:
+            e.load_resnet(blob)
+            p, v = e.predict(np.stack(boards))
+        err_p, err_v = np.max(np.abs(p - pt)), np.max(np.abs(v - vt))
+        print(f"[net-error] BASELINE net {game} {blocks}x{ch} f16x2={f16}: max |dp| = {err_p:.2e}, max |dv| = {err_v:.2e}")
+        assert err_p < NORTH_STAR_TOL and err_v < NORTH_STAR_TOL
+        assert np.all(p[mask == 0] == 0)
 
 
 @pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
@@ -274,11 +326,10 @@ def test_resnet_every_batch_regime_returns_the_same_bits(azsp, blocks, ch, f16):
     assert np.array_equal(p_perm, p_big[perm]) and np.array_equal(v_perm, v_big[perm])
     assert np.array_equal(p_odd, p_big[:1003]) and np.array_equal(v_odd, v_big[:1003])
     assert np.array_equal(p_small, p_big) and np.array_equal(v_small, v_big)
-    with torch.no_grad():                                     # and all of it is the network (tolerance as elsewhere)
-        logits, vl = net.forward(net._states_to_tensor(list(boards[:64])))
-        mask = torch.tensor([rules.valid_moves(b) for b in boards[:64]])
-        pt = torch.softmax(logits.masked_fill(mask == 0, float("-inf")), dim=1).numpy()
-    assert np.max(np.abs(p_big[:64] - pt)) < 1e-5 and np.max(np.abs(v_big[:64] - torch.tanh(vl).numpy())) < 1e-5
+    pt, vt, _ = _torch_reference(net, rules, list(boards[:64]))    # and all of it is the network (tolerance as elsewhere)
+    err_p, err_v = np.max(np.abs(p_big[:64] - pt)), np.max(np.abs(v_big[:64] - vt))
+    print(f"[net-error] connect4 {blocks}x{ch} f16x2={f16} (all batch regimes): max |dp| = {err_p:.2e}, max |dv| = {err_v:.2e}")
+    assert err_p < NET_TOL and err_v < NET_TOL
 
 
 # ------------------------------------------------------------------------------------ full size
@@ -300,6 +351,212 @@ def test_full_size_config2_properties(azsp):
     st = gen.last_stats
     assert st["rounds"] == st["plies"] * (sims + 1)
     assert st["evals"] + st["terminal_leaves"] == st["plies"] * n * (sims + 1)
+
+
+def _full_size_invariants(azsp, game, rules, net, n, sims, stride, **gen_kw):
+    np.random.seed(0)
+    gen = azsp.EpisodeGenerator(game=game, config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), **gen_kw)
+    eps = list(gen.generate_episodes(net))
+    assert len(eps) == n
+    for ep in eps[::stride]:
+        check_episode_invariants(rules, np.stack([s.state for s in ep.samples]),
+                                 np.stack([s.policy for s in ep.samples]), [s.value for s in ep.samples], sims)
+    st = gen.last_stats
+    assert st["rounds"] == st["plies"] * (sims + 1)
+    assert st["evals"] + st["terminal_leaves"] == st["plies"] * n * (sims + 1)
+    return eps, st
+
+
+def test_full_size_config3_properties(azsp):
+    """BASELINE.json configs[2]: Connect-4, 64-ch/4-block ResNet, 400 sims, 8192 concurrent games on one GPU (the
+    deep-tree backup stress: up to 2808 nodes per tree, 0.46 GB of trees), through the same invariants as config 2."""
+    import torch
+    torch.manual_seed(0)
+    net = azsp.ResNet((6, 7), 7, 4, 64)
+    eps, st = _full_size_invariants(azsp, azsp.Connect4Game(), oz.C4Rules(), net, 8192, 400, 23)
+    assert st["path_nodes"] / (st["evals"] + st["terminal_leaves"]) > 3.0      # deeper trees than at 100 sims
+
+
+def test_full_size_config4_one_gpu_shard_properties(azsp):
+    """BASELINE.json configs[3], the share of ONE of its 8 GPUs: Connect-4, 128-ch/8-block ResNet, 100 sims, 4096
+    concurrent games (32768 games / 8; the shards are independent replicas)."""
+    import torch
+    torch.manual_seed(0)
+    net = azsp.ResNet((6, 7), 7, 8, 128)
+    _full_size_invariants(azsp, azsp.Connect4Game(), oz.C4Rules(), net, 4096, 100, 11)
+
+
+def test_config4_network_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp):
+    """configs[3]'s network (8 blocks x 128 channels) in the loop, at a size the oracle finishes: 32 games x 100 sims;
+    the C oracle asks the device kernel for (P, V), so counts, moves, pi, z and the RNG position must be identical."""
+    import torch
+    from azsp.weights import resnet_blob
+    torch.manual_seed(3)
+    net = azsp.ResNet((6, 7), 7, 8, 128).eval()
+    blob, blocks, ch = resnet_blob(net)
+    n, sims, seed = 32, 100, 5
+    with _engine(azsp, "connect4", 64, 1, res_blocks=blocks, channels=ch) as pe:
+        pe.load_resnet(blob)
+        cb = co.make_predict_cb(lambda bs: pe.predict(np.stack(bs)), (6, 7), 7)
+        ref = co.generate("connect4", sims, n, seed=seed, predict_cb=cb, trace=False)
+    np.random.seed(seed)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    eps = list(gen.generate_episodes(net))
+    assert float(np.random.random_sample()) == ref["next_uniform"]
+    _assert_equals_c_oracle(eps, ref, n)
+
+
+def _assert_equals_c_oracle(eps, ref, n):
+    assert len(eps) == n == ref["n_episodes"]
+    for e, ep in enumerate(eps):
+        lo, hi = ref["ep_offset"][e], ref["ep_offset"][e + 1]
+        assert np.array_equal(np.stack([s.state for s in ep.samples]).reshape(hi - lo, -1), ref["states"][lo:hi])
+        assert np.array_equal(np.stack([s.policy for s in ep.samples]), ref["policies"][lo:hi])
+        assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()
+
+
+def test_full_size_config5_one_gpu_shard_properties(azsp):
+    """BASELINE.json configs[4] on one GPU: 9x9 Gomoku through the Game plugin, 256-ch/10-block ResNet, 200 sims/move;
+    192 concurrent games in two slot groups (a shard sized for the test's time budget), checked through the
+    size-independent invariants (pi * sims integral, move chains, outcome / z consistency, evaluation accounting)."""
+    import torch
+    torch.manual_seed(0)
+    net = azsp.ResNet((9, 9), 81, 10, 256)
+    _full_size_invariants(azsp, azsp.GomokuGame(), oz.G9Rules(), net, 192, 200, 5, n_groups=2)
+
+
+def test_config5_network_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp):
+    """configs[4]'s network (10 blocks x 256 channels, 9x9) in the loop at oracle size: 6 games x 24 sims."""
+    import torch
+    from azsp.weights import resnet_blob
+    torch.manual_seed(9)
+    net = azsp.ResNet((9, 9), 81, 10, 256).eval()
+    blob, blocks, ch = resnet_blob(net)
+    n, sims, seed = 6, 24, 8
+    with _engine(azsp, "gomoku9", 64, 1, res_blocks=blocks, channels=ch) as pe:
+        pe.load_resnet(blob)
+        cb = co.make_predict_cb(lambda bs: pe.predict(np.stack(bs)), (9, 9), 81)
+        ref = co.generate("gomoku9", sims, n, seed=seed, predict_cb=cb, trace=False)
+    np.random.seed(seed)
+    gen = azsp.EpisodeGenerator(game=azsp.GomokuGame(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    eps = list(gen.generate_episodes(net))
+    assert float(np.random.random_sample()) == ref["next_uniform"]
+    _assert_equals_c_oracle(eps, ref, n)
+
+
+@pytest.mark.parametrize("blocks,ch", [(2, 32), (1, 128)])
+def test_gomoku_device_network_with_several_slot_groups(azsp, blocks, ch):
+    """Slot groups run on separate streams and share the evaluator's output array, one stripe of n_act rows of the
+    game's padded action width (88 floats for Gomoku, 8 for Connect-4) per group.  128 games of Gomoku with the device
+    network must come out identical with 1, 2 and 4 groups and equal to the C oracle fed by the same kernel."""
+    import torch
+    from azsp.weights import resnet_blob
+    torch.manual_seed(ch)
+    net = azsp.ResNet((9, 9), 81, blocks, ch).eval()
+    blob, _, _ = resnet_blob(net)
+    n, sims, seed = 128, 12, 3
+    with _engine(azsp, "gomoku9", 256, 1, res_blocks=blocks, channels=ch) as pe:
+        pe.load_resnet(blob)
+        cb = co.make_predict_cb(lambda bs: pe.predict(np.stack(bs)), (9, 9), 81)
+        ref = co.generate("gomoku9", sims, n, seed=seed, predict_cb=cb, trace=False)
+    boards = np.stack(random_midgame_boards(oz.G9Rules(), np.random.RandomState(5), 128, 50))
+    searched = []
+    for groups in (1, 2, 4):
+        np.random.seed(seed)
+        gen = azsp.EpisodeGenerator(game=azsp.GomokuGame(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), n_groups=groups)
+        eps = list(gen.generate_episodes(net))
+        assert float(np.random.random_sample()) == ref["next_uniform"], groups
+        _assert_equals_c_oracle(eps, ref, n)
+        with _engine(azsp, "gomoku9", 128, 40, res_blocks=blocks, channels=ch, n_groups=groups) as e:
+            e.load_resnet(blob)
+            searched.append(e.run_batch(boards))
+    for other in searched[1:]:
+        for k in ("counts", "child_w", "prior", "root_w", "root_n"):
+            assert np.array_equal(searched[0][k], other[k]), k
+
+
+def test_real_network_transcript_of_the_reference_config1(azsp):
+    """tests/golden/episodes_resnet.json: the REFERENCE's generate_episodes with its own torch-CPU ResNet(4, 64)
+    (BASELINE.json configs[0]: 25 sims, one game, seeds 0 / 0; episode_generator.py:23-87 + resnet.py:130-157).  The
+    engine plays the same game with the same weights on the device network: per-ply root visit counts, chosen moves,
+    pi, z and the RNG position must be the reference's.  The two networks agree to ~1e-7, not bitwise, so a ply may
+    legitimately differ only where the search passed through a near-tie: everything up to such a ply must be equal,
+    and the PUCT margin there (oracle search fed by the device network) must be below 1e-6 -- it is printed."""
+    from helpers import min_puct_margin
+    from azsp.weights import resnet_blob
+    run = load_json("episodes_resnet.json")
+    z, sd = _golden_net("m")               # ResNet((6, 7), 7, 4, 64) after torch.manual_seed(0): the transcript's network
+    assert z["m_arch"].tolist() == run["arch"] and run["torch_seed"] == 0
+    blob, blocks, ch = resnet_blob({k: v for k, v in sd.items() if "num_batches_tracked" not in k})
+    n, sims = run["n"], run["sims"]
+    rules = oz.C4Rules()
+    np.random.seed(run["seed"])
+    states, pols = [], []
+    with _engine(azsp, "connect4", n, sims, res_blocks=blocks, channels=ch) as e:
+        e.load_resnet(blob)
+        e.reset()
+        board, player = rules.init_board(), 1
+        for k, ply in enumerate(run["plies"]):
+            e.search()
+            counts = e.root_counts()[0].tolist()
+            if counts != ply["counts"][0]:
+                with _engine(azsp, "connect4", 64, 1, res_blocks=blocks, channels=ch) as pe:
+                    pe.load_resnet(blob)
+                    gap = min_puct_margin(rules, lambda bs: tuple(map(list, pe.predict(np.stack(bs)))), sims,
+                                          rules.canonical(board, player))
+                print(f"[transcript] ply {k}: device-network counts {counts} vs reference {ply['counts'][0]}; "
+                      f"smallest PUCT margin in this search = {gap:.3e}")
+                assert gap < 1e-6, "the searches differ although no selection step was a near-tie"
+                pytest.xfail(f"transcript equal up to ply {k}; ply {k} passes through a PUCT near-tie ({gap:.1e})")
+            states.append(rules.canonical(board, player).tolist())
+            pols.append((np.array(counts) / np.sum(counts)).tolist())
+            res = e.play(np.random.random_sample(n))
+            out = e.fetch_episodes(0, res.n_finished) if res.n_finished else None
+            board, player = rules.next_state(board, player, ply["actions"][0])
+        assert res.finished and res.episodes_total == 1 and len(run["plies"]) == len(states)
+    g = run["episodes"][0]
+    assert states == g["states"] and pols == g["policies"]
+    assert out["states"].reshape(-1, 6, 7).tolist() == g["states"] and out["policies"].tolist() == g["policies"]
+    assert out["values"].tolist() == g["values"]
+    assert float(np.random.random_sample()) == run["rng_after"]
+    # and through the drop-in generator, as the training loop would call it
+    class Net:
+        def state_dict(self):
+            return {k: v for k, v in sd.items() if "num_batches_tracked" not in k}
+    np.random.seed(run["seed"])
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    _episodes_equal(list(gen.generate_episodes(Net())), run["episodes"])
+    assert float(np.random.random_sample()) == run["rng_after"]
+
+
+def test_device_dataset_and_json_writer_match_reference_output(azsp, tmp_path):
+    """SURVEY 8f rank 1 and 2 pinned by the reference's own output: tests/golden/format_dataset.npz holds the tensors
+    the reference's BaseModel.format_dataset / ResNet._states_to_tensor built (base_model.py:61-67, resnet.py:115-128)
+    and tests/golden/episodes_wire.json the file its DataModule._save_episodes wrote (episode.py:15-24,64-66,
+    datamodule.py:87-96) for one of its generator runs.  The engine repeats that run (hash evaluator, same seed):
+    azsp_export_dataset_device must give those tensors and save_episodes that file, bit for bit / byte for byte."""
+    import json
+    import os
+    import torch
+    from helpers import GOLDEN
+    from azsp.replay import generate_dataset, load_episodes, save_episodes
+    z = np.load(os.path.join(GOLDEN, "format_dataset.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    text = open(os.path.join(GOLDEN, "episodes_wire.json")).read()
+    cfg = azsp.AlphaZeroConfig(32, 1, meta["sims"], meta["n"], 1, 1)
+    model = HashStub(meta["game"], meta["salt"])
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg)
+    np.random.seed(meta["seed"])
+    ds = generate_dataset(gen, model)
+    assert float(np.random.random_sample()) == meta["rng_after"]
+    assert [str(t.dtype) for t in ds.tensors] == meta["dtypes"] and [list(t.shape) for t in ds.tensors] == meta["shapes"]
+    for t, k in zip(ds.tensors, ("planes", "policies", "values")):
+        assert t.is_cuda and torch.equal(t.cpu(), torch.from_numpy(z[k])), k
+    np.random.seed(meta["seed"])
+    eps = list(gen.generate_episodes(model))
+    save_episodes(tmp_path / "episodes_iter1.json", eps)
+    assert open(tmp_path / "episodes_iter1.json").read() == text
+    assert load_episodes(os.path.join(GOLDEN, "episodes_wire.json")) == eps
 
 
 def test_error_paths(azsp):
@@ -542,11 +799,12 @@ def test_gomoku_generate_matches_c_oracle_at_larger_sizes(azsp, n, sims, seed, s
         assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()
 
 
-@pytest.mark.parametrize("blocks,ch", [(2, 32), (3, 64), (2, 96), (2, 128), (1, 192), (2, 256)])
+@pytest.mark.parametrize("blocks,ch", [(2, 32), (3, 64), (2, 96), (2, 128), (1, 192), (2, 256), (10, 256)])
 def test_gomoku_resnet_predict_on_device(azsp, blocks, ch):
     """The same ResNet architecture on the 9x9 plugin game (policy Linear 32*81 -> 81, legal = empty cells).
     The reference's ResNet.predict cannot mask a 9x9 board, so the check is against this module's own PyTorch
-    forward on the CPU (tolerance 1e-5) -- parity is not pinnable by the reference here."""
+    forward on the CPU (tolerance NET_TOL_WIDE; (10, 256) is BASELINE configs[4]'s network) -- parity is not pinnable
+    by the reference here."""
     import torch
     torch.manual_seed(7 * blocks + ch)
     net = azsp.ResNet((9, 9), 81, blocks, ch)
@@ -554,14 +812,12 @@ def test_gomoku_resnet_predict_on_device(azsp, blocks, ch):
     rules = oz.G9Rules()
     boards = random_midgame_boards(rules, np.random.RandomState(3), 10, 60)
     p, v = net.predict(boards)
-    with torch.no_grad():
-        logits, vl = net.forward(net._states_to_tensor(boards))
-        mask = torch.tensor([rules.valid_moves(b) for b in boards])
-        pt = torch.softmax(logits.masked_fill(mask == 0, float("-inf")), dim=1).numpy()
-        vt = torch.tanh(vl).numpy()
+    pt, vt, mask = _torch_reference(net, rules, boards)
     assert np.stack(p).shape == (10, 81)
-    assert np.max(np.abs(np.stack(p) - pt)) < 1e-5 and np.max(np.abs(np.array(v) - vt)) < 1e-5
-    assert np.all(np.stack(p)[mask.numpy() == 0] == 0)
+    err_p, err_v = np.max(np.abs(np.stack(p) - pt)), np.max(np.abs(np.array(v) - vt))
+    print(f"[net-error] gomoku9 {blocks}x{ch}: max |dp| = {err_p:.2e}, max |dv| = {err_v:.2e}")
+    assert err_p < NET_TOL and err_v < NET_TOL
+    assert np.all(np.stack(p)[mask == 0] == 0)
 
 
 def test_gomoku_self_play_with_device_network_bit_exact_vs_oracle(azsp):

@@ -66,6 +66,20 @@ def test_gen1_search_statistics_bit_exact(gen1, sims, c_puct):
         assert node.value == ref.value
 
 
+def test_gen1_second_run_on_a_used_node_is_refused(gen1):
+    """search.py:66-91 continues a node's existing tree when run() is called again; the device search cannot (it starts
+    from an unexpanded root), so a used Node is refused instead of being restarted with mismatched statistics."""
+    from azsp import connect_state as cs
+    search = gen1.AlphaZeroSearch(model=gen1.HashModel(3), num_simulations=20)
+    root = gen1.Node(cs.Config().sample_initial_state())
+    policy, _ = search.run(root)
+    assert abs(sum(policy.values()) - 1.0) < 1e-12 and root.visit_count == 20
+    with pytest.raises(ValueError, match="fresh nodes"):
+        search.run(root)
+    again, _ = search.run(gen1.Node(root.state))          # a new Node on the same state is the supported way
+    assert again == policy
+
+
 def _compare_episodes(eps, ref):
     assert len(eps) == len(ref)
     for ep, r in zip(eps, ref):

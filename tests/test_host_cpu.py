@@ -124,6 +124,52 @@ def test_episode_json_wire_format_roundtrip(tmp_path):
             assert np.array_equal(x.state, y.state) and np.array_equal(x.policy, y.policy) and x.value == y.value
 
 
+def _wire_fixture():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "format_dataset.npz"))
+    meta = __import__("json").loads(bytes(z["meta"]).decode())
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "episodes_wire.json")).read()
+    return z, meta, text
+
+
+def test_json_writer_and_loader_match_the_reference_written_file(tmp_path):
+    """tests/golden/episodes_wire.json is the text the REFERENCE's DataModule._save_episodes wrote for one of its own
+    generator runs (Episode.to_dict + json.dump, episode.py:15-24,64-66, datamodule.py:87-96).  The same run's
+    episodes (fixture episodes_hash.json, n = 16) written by azsp.replay.save_episodes must give that file byte for
+    byte, and load_episodes must parse the reference's file into what Episode.from_dict gives there
+    (int64 boards, float64 policies, int values)."""
+    from azsp.replay import load_episodes, save_episodes
+    z, meta, text = _wire_fixture()
+    run = [r for r in load_json("episodes_hash.json")["runs"]
+           if (r["game"], r["n"], r["sims"], r["seed"], r["salt"]) == ("connect4", meta["n"], meta["sims"], meta["seed"], meta["salt"])][0]
+    eps = [azsp.Episode(samples=[azsp.Sample(np.array(s, dtype=np.int64), np.array(p, dtype=np.float64), int(v))
+                                 for s, p, v in zip(g["states"], g["policies"], g["values"])]) for g in run["episodes"]]
+    path = tmp_path / "episodes_iter1.json"
+    save_episodes(path, eps)
+    assert open(path).read() == text
+    back = load_episodes(os.path.join(os.path.dirname(__file__), "golden", "episodes_wire.json"))
+    assert [len(e) for e in back] == meta["loaded"]["lengths"]
+    s0 = back[0].samples[0]
+    assert str(s0.state.dtype) == meta["loaded"]["state_dtype"] and str(s0.policy.dtype) == meta["loaded"]["policy_dtype"]
+    assert type(s0.value).__name__ == meta["loaded"]["value_type"] and list(s0.state.shape) == meta["loaded"]["state_shape"]
+    assert back == eps
+    save_episodes(path, back)                     # load -> save is the identity on the reference's file
+    assert open(path).read() == text
+
+
+def test_host_format_dataset_matches_reference_tensors():
+    """BaseModel.format_dataset + ResNet._states_to_tensor of the host mirror vs the tensors the reference's own
+    methods produced from the same samples (base_model.py:61-67, resnet.py:115-128), bit for bit."""
+    import torch
+    z, meta, text = _wire_fixture()
+    eps = [azsp.Episode.from_dict(d) for d in __import__("json").loads(text)]
+    samples = [s for e in eps for s in e.samples]
+    ds = azsp.ResNet((6, 7), 7, 1, 16).format_dataset([s.state for s in samples], [s.policy for s in samples],
+                                                      [s.value for s in samples])
+    assert [str(t.dtype) for t in ds.tensors] == meta["dtypes"] and [list(t.shape) for t in ds.tensors] == meta["shapes"]
+    for t, k in zip(ds.tensors, ("planes", "policies", "values")):
+        assert torch.equal(t, torch.from_numpy(z[k]))
+
+
 def test_shard_allowances_reproduce_the_global_first_n_rule():
     """Brute-force check of the per-ply bookkeeping of the sharded exact mode against a flat slot scan."""
     from azsp.sharded import shard_allowances, shard_ranges
