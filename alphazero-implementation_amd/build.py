@@ -23,9 +23,14 @@ UNITS = {
     "azsp_tree.hip": ["-ffp-contract=off"],
     "azsp_engine.hip": ["-ffp-contract=off"],
     "azsp_resnet.hip": [],
+    "azsp_resnet_k1.hip": ["-ftemplate-depth=2048"],     # kernel instantiations (csrc/azsp_resnet_kernel.h), split so that
+    "azsp_resnet_k2.hip": ["-ftemplate-depth=2048"],     # the statically scheduled towers compile side by side
+    "azsp_resnet_k3.hip": [],
+    "azsp_resnet_k4.hip": [],
     "azsp_resnet_f16.hip": [],
 }
-HEADERS = ["azsp_internal.h", "azsp_games.h", "azsp_resnet_host.h", os.path.join("..", "..", "include", "azsp.h")]
+HEADERS = ["azsp_internal.h", "azsp_games.h", "azsp_resnet_host.h", "azsp_resnet_kernel.h",
+           os.path.join("..", "..", "include", "azsp.h")]
 
 
 def hipcc() -> str:
@@ -41,7 +46,7 @@ def newer(a: str, b: str) -> bool:
 
 def build(force: bool = False, save_temps: bool = False) -> str:
     cc = hipcc()
-    objs = []
+    objs, jobs = [], []
     hdr_paths = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     for src, extra in UNITS.items():
         s = os.path.join(CSRC, src)
@@ -50,9 +55,16 @@ def build(force: bool = False, save_temps: bool = False) -> str:
             cmd = [cc, *COMMON, *extra, "-c", s, "-o", o]
             if save_temps:
                 cmd.insert(1, "-save-temps=obj")
+            jobs.append(cmd)
+        objs.append(o)
+    if jobs:                                   # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd, cwd=CSRC)
-        objs.append(o)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) - 1))) as pool:
+            list(pool.map(run, jobs))
     if force or any(newer(o, OUT) for o in objs):
         cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT, *objs]
         print(" ".join(cmd), flush=True)

@@ -9,6 +9,8 @@
 //       values a lane needs for four consecutive k-steps; the reads of a 16-MFMA half block are issued up front
 //   V2  V1 + weights double-buffered by half tap (the next half tap's four loads are issued before this one's MFMAs)
 //   V4  V2 with the four row tiles interleaved per quad of k-steps (rotating accumulators) instead of one block per tile
+//   V5  one static, role-specialised instruction sequence per layer: A reads two steps ahead, next tap's weights in a second buffer
+//   V6  V5 with ONE weight buffer: the tap's last tile block reloads each quad for the next tap as soon as it has used it
 // ROWS = 0: LDS rows in board order (conflict-free), ROWS = 1: the shipped tap-skipping row order (bank conflicts).
 //   hipcc --offload-arch=gfx950 -O3 -o tower_loop tower_loop.hip && ./tower_loop
 #include <hip/hip_runtime.h>
@@ -37,7 +39,85 @@ __device__ __forceinline__ unsigned need_of(int group, int tile) {
     return tile == 0 ? (0x1FFu & ~0x007u) : (0x1FFu & ~0x1C0u);                     // lacks dy = -1 : taps 0,1,2 / dy = +1 : 6,7,8
 }
 
-template <int V, int STRIDE>
+
+// ---- V5: role-specialised static schedule -------------------------------------------------------------------------
+// The tile-tap masks are a static property of the row order, so the layer body is specialised on the wave's row group
+// and written as one straight-line sequence of 240 steps (tile-tap x quad of k-steps).  Step i issues the 16-byte A read
+// of step i + 2 (three rotating buffers) and then its own four MFMAs; the eight weight quads of the NEXT tap are loaded
+// into a second buffer while the current tap is computed, one load at the head of every fourth step.
+// __builtin_amdgcn_sched_barrier(0) between steps keeps the compiler from re-serialising reads and MFMAs.
+struct Step { int tap, tile, q, first_of_tap, last_tile; };
+template <int GROUP>
+struct Sched {
+    Step s[240 + 2];
+    int n;
+    constexpr Sched() : s{}, n(0) {
+        for (int tap = 0; tap < 9; ++tap) {
+            int first = 1;
+            for (int tile = 3; tile >= 0; --tile) {
+                unsigned need = tile >= 2 ? 0x1FFu : (GROUP == 0 ? (tile == 0 ? (0x1FFu & ~0x049u) : (0x1FFu & ~0x124u))
+                                                                  : (tile == 0 ? (0x1FFu & ~0x007u) : (0x1FFu & ~0x1C0u)));
+                if (!((need >> tap) & 1u)) continue;
+                for (int q = 0; q < 8; ++q) { s[n].tap = tap; s[n].tile = tile; s[n].q = q; s[n].first_of_tap = first && q == 0; s[n].last_tile = 0; ++n; }
+                first = 0;
+            }
+            for (int q = 0; q < 8; ++q) s[n - 8 + q].last_tile = 1;        // the tap's last tile block
+        }
+        s[n] = s[n - 1]; s[n + 1] = s[n - 1];       // harmless over-reads past the end
+    }
+};
+
+template <int GROUP>
+struct SchedHolder { static constexpr Sched<GROUP> SC{}; };
+
+template <int GROUP, int STRIDE, int PAR, int I>
+__device__ __forceinline__ void step_v5(f32x16 (&acc)[4], const float *lds, const int (&ridx)[4], const float *wl,
+                                        float4 (&wb)[2][8], float4 (&xa)[3]) {
+    constexpr Step st = SchedHolder<GROUP>::SC.s[I], nx = SchedHolder<GROUP>::SC.s[I + 2];
+    constexpr int cur = (st.tap + PAR) & 1;
+    constexpr bool wload = SchedHolder<GROUP>::SC.s[I - st.q].first_of_tap != 0;      // quad q of the tap's first tile
+    xa[(I + 2) % 3] = *reinterpret_cast<const float4 *>(lds + 8 * STRIDE + ridx[nx.tile] + ((nx.tap / 3 - 1) * 7 + (nx.tap % 3 - 1)) * STRIDE + 8 * nx.q);
+    if constexpr (wload)
+        wb[cur ^ 1][st.q] = *reinterpret_cast<const float4 *>(wl + (size_t)((st.tap + 1) * 8 + st.q) * 2 * 64 * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[st.tile] = MF(comp(xa[I % 3], k), comp(wb[cur][st.q], k), acc[st.tile]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I + 1 < 240) step_v5<GROUP, STRIDE, PAR, I + 1>(acc, lds, ridx, wl, wb, xa);
+}
+
+template <int GROUP, int STRIDE, int I>
+__device__ __forceinline__ void step_v6(f32x16 (&acc)[4], const float *lds, const int (&ridx)[4], const float *wl,
+                                        float4 (&wb)[8], float4 (&xa)[3]) {
+    constexpr Step st = SchedHolder<GROUP>::SC.s[I], nx = SchedHolder<GROUP>::SC.s[I + 2];
+    xa[(I + 2) % 3] = *reinterpret_cast<const float4 *>(lds + 8 * STRIDE + ridx[nx.tile] + ((nx.tap / 3 - 1) * 7 + (nx.tap % 3 - 1)) * STRIDE + 8 * nx.q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[st.tile] = MF(comp(xa[I % 3], k), comp(wb[st.q], k), acc[st.tile]);
+    // the tap's last tile has consumed quad q: the same registers take the next tap's quad q (needed eight steps later)
+    if constexpr (st.last_tile != 0)
+        wb[st.q] = *reinterpret_cast<const float4 *>(wl + (size_t)((st.tap + 1) * 8 + st.q) * 2 * 64 * 4);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I + 1 < 240) step_v6<GROUP, STRIDE, I + 1>(acc, lds, ridx, wl, wb, xa);
+}
+
+template <int GROUP, int STRIDE>
+__device__ __forceinline__ void layer_v6(f32x16 (&acc)[4], const float *lds, const int (&ridx)[4], const float *wl, float4 (&wb)[8]) {
+    float4 xa[3];
+    constexpr Step s0 = SchedHolder<GROUP>::SC.s[0], s1 = SchedHolder<GROUP>::SC.s[1];
+    xa[0] = *reinterpret_cast<const float4 *>(lds + 8 * STRIDE + ridx[s0.tile] + ((s0.tap / 3 - 1) * 7 + (s0.tap % 3 - 1)) * STRIDE + 8 * s0.q);
+    xa[1] = *reinterpret_cast<const float4 *>(lds + 8 * STRIDE + ridx[s1.tile] + ((s1.tap / 3 - 1) * 7 + (s1.tap % 3 - 1)) * STRIDE + 8 * s1.q);
+    step_v6<GROUP, STRIDE, 0>(acc, lds, ridx, wl, wb, xa);
+}
+
+template <int GROUP, int STRIDE, bool XR, int PAR>
+__device__ __forceinline__ void layer_v5(f32x16 (&acc)[4], const float *lds, const int (&ridx)[4], const float *wl, float4 (&wb)[2][8]) {
+    float4 xa[3];
+    constexpr Step s0 = SchedHolder<GROUP>::SC.s[0], s1 = SchedHolder<GROUP>::SC.s[1];
+    xa[0] = *reinterpret_cast<const float4 *>(lds + 8 * STRIDE + ridx[s0.tile] + ((s0.tap / 3 - 1) * 7 + (s0.tap % 3 - 1)) * STRIDE + 8 * s0.q);
+    xa[1] = *reinterpret_cast<const float4 *>(lds + 8 * STRIDE + ridx[s1.tile] + ((s1.tap / 3 - 1) * 7 + (s1.tap % 3 - 1)) * STRIDE + 8 * s1.q);
+    step_v5<GROUP, STRIDE, PAR, 0>(acc, lds, ridx, wl, wb, xa);
+}
+
+template <int V, int STRIDE, bool XR = false>
 __global__ __launch_bounds__(256, 2) void probe(Params P) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, wave = tid >> 6;
@@ -54,9 +134,29 @@ __global__ __launch_bounds__(256, 2) void probe(Params P) {
         need[t] = need_of(group, t);
     }
     const float *wbase = P.w + ((size_t)wc * 64 + lane) * 4;
+    f32x16 xres[4];                                 // the shipped kernel keeps the residual in 64 registers across a block
+    if constexpr (XR) for (int t = 0; t < 4; ++t) for (int v = 0; v < 16; ++v) xres[t][v] = lds[(t * 16 + v) * 3 + lane];
+    float4 wb[2][8];
+    if constexpr (V == 5 || V == 6) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wb[0][q] = *reinterpret_cast<const float4 *>(wbase + (size_t)q * 2 * 64 * 4);
+    }
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int layer = 0; layer < LAYERS; ++layer) {
         const float *wl = wbase + (size_t)layer * TAPS * NQ * 2 * 64 * 4;
+        if constexpr (XR) if (layer & 1) for (int t = 0; t < 4; ++t) for (int v = 0; v < 16; ++v) { acc[t][v] += xres[t][v]; xres[t][v] = fmaxf(acc[t][v], 0.0f); }
+        if constexpr (V == 6) {
+            if (group == 0) layer_v6<0, STRIDE>(acc, lds, ridx, wl, wb[0]); else layer_v6<1, STRIDE>(acc, lds, ridx, wl, wb[0]);
+            __syncthreads();
+            continue;
+        }
+        if constexpr (V == 5) {
+            // nine taps per layer: the buffer parity of tap 0 alternates from layer to layer
+            if (group == 0) { if (layer & 1) layer_v5<0, STRIDE, XR, 1>(acc, lds, ridx, wl, wb); else layer_v5<0, STRIDE, XR, 0>(acc, lds, ridx, wl, wb); }
+            else { if (layer & 1) layer_v5<1, STRIDE, XR, 1>(acc, lds, ridx, wl, wb); else layer_v5<1, STRIDE, XR, 0>(acc, lds, ridx, wl, wb); }
+            __syncthreads();
+            continue;
+        }
         if constexpr (V == 0) {
             for (int tap = 0; tap < TAPS; ++tap) {
                 const int off = ((tap / 3 - 1) * 7 + (tap % 3 - 1)) * STRIDE;
@@ -176,18 +276,18 @@ static void build_row_order(int *q) {     // the shipped 2 x 2 table (azsp_resne
     }
 }
 
-template <int V, int STRIDE>
+template <int V, int STRIDE, bool XR = false>
 static void run(const char *name, int rows_mode, int wg_per_cu, Params P, const int *d_perm_id, const int *d_perm_sk) {
     const int grid = 256 * wg_per_cu;
     P.perm = rows_mode ? d_perm_sk : d_perm_id;
     const size_t lds = (size_t)(WG_ROWS + 16) * STRIDE * 4 + (wg_per_cu == 1 ? 84000 : 0);    // force one workgroup per CU by LDS size
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&probe<V, STRIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int rep = 0; rep < 300; ++rep) probe<V, STRIDE><<<grid, 256, lds>>>(P);     // warm the clock
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&probe<V, STRIDE, XR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int rep = 0; rep < 300; ++rep) probe<V, STRIDE, XR><<<grid, 256, lds>>>(P);     // warm the clock
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    for (int rep = 0; rep < 20; ++rep) probe<V, STRIDE><<<grid, 256, lds>>>(P);
+    for (int rep = 0; rep < 20; ++rep) probe<V, STRIDE, XR><<<grid, 256, lds>>>(P);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms = 0;
@@ -222,6 +322,11 @@ int main() {
             run<1, 68>("V1 ds_read_b128, 4 reads per half block", rows, k, P, pid, psk);
             run<2, 68>("V2 V1 + weights double-buffered per half tap", rows, k, P, pid, psk);
             run<4, 68>("V4 V2 with tiles interleaved per quad", rows, k, P, pid, psk);
+            run<0, 65, true>("V0 + 64 residual registers live", rows, k, P, pid, psk);
+            run<5, 68>("V5 static schedule, A and B pipelined", rows, k, P, pid, psk);
+            run<5, 68, true>("V5 + 64 residual registers live", rows, k, P, pid, psk);
+            run<6, 68>("V6 static schedule, one weight buffer refreshed in place", rows, k, P, pid, psk);
+            run<6, 68, true>("V6 + 64 residual registers live", rows, k, P, pid, psk);
         }
     return 0;
 }
