@@ -106,6 +106,8 @@ struct azsp_engine {
     float *d_st_w = nullptr, *d_st_rw = nullptr;
     double *d_st_prior = nullptr;
     double *d_noise = nullptr;        // root exploration noise staging
+    float *d_stage_p = nullptr, *d_stage_v = nullptr;   // host evaluator: results in list order before the scatter to slots
+    size_t leaf_off = 0;              // byte offset of the leaf position inside a slot record
     double *d_st_wd = nullptr, *d_st_rwd = nullptr;   // float64 root statistics staging
     double *d_sqrt = nullptr, *d_ctab = nullptr, *d_expl = nullptr;   // [n_sims + 2] exploration tables
     double c_init = 1.0, c_base = 0.0;
@@ -200,8 +202,9 @@ static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
         case AZSP_EVAL_RESNET: {
             if (!e->net || !e->net_loaded) return fail(AZSP_ERR_STATE, "ResNet evaluator selected but no weights loaded (azsp_load_resnet)");
             EventPair *p = ev_begin(e, EV_INFER, st);
-            resnet_forward(e->net, game, v.leaf_mine, v.leaf_theirs, v.leaf_slot + v.lo, v.nl, v.n_act,
-                           v.eval_p + (size_t)v.lo * e->gi.AP, v.eval_v + v.lo, st);   // rows of the game's padded width AP
+            // leaf positions sit in the slot records; outputs are indexed by slot, so groups never share rows
+            resnet_forward(e->net, game, reinterpret_cast<const u64 *>(v.slot + e->leaf_off), v.slot_bytes / 8, v.leaf_slot + v.lo, v.nl,
+                           v.n_act, v.eval_p, v.eval_v, st);
             ev_end(p, st);
             e->stats.infer_launches++;
             return 0;
@@ -221,8 +224,9 @@ static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
                 return fail(AZSP_ERR_CALLBACK, "host evaluator callback reported failure");
             for (int j = 0; j < m; ++j)
                 for (int a = 0; a < AP; ++a) e->h_p8[(size_t)j * AP + a] = a < A ? e->h_p[(size_t)j * A + a] : 0.0f;
-            HIP_TRY(hipMemcpyAsync(v.eval_p, e->h_p8.data(), (size_t)m * AP * sizeof(float), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(v.eval_v, e->h_v.data(), (size_t)m * sizeof(float), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(e->d_stage_p, e->h_p8.data(), (size_t)m * AP * sizeof(float), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(e->d_stage_v, e->h_v.data(), (size_t)m * sizeof(float), hipMemcpyHostToDevice, st));
+            launch_scatter_eval(game, v, e->d_stage_p, e->d_stage_v, st);      // list order -> slot order
             HIP_TRY(hipStreamSynchronize(st));
             return 0;
         }
@@ -443,32 +447,40 @@ static int create_impl(azsp_engine *e) {
     v.reuse = (c.flags & AZSP_FLAG_TREE_REUSE) ? 1 : 0;
     v.E = v.reuse ? (S + 1) * gi.max_plies : S + 1;
     v.C = ((1 + A * v.E) + 7) & ~7;
-    v.D = (!v.reuse && S + 2 < gi.max_plies + 2) ? S + 2 : gi.max_plies + 2;
     v.max_plies = gi.max_plies;
     v.cells = gi.cells;
-    const size_t NC = (size_t)N * v.C, NE = (size_t)N * v.E;
-    DEV_ALLOC(v.cnt, NC); DEV_ALLOC(v.wsum, NC); DEV_ALLOC(v.prior, NC); DEV_ALLOC(v.kids, NC);
-    DEV_ALLOC(v.blk_parent, NE); DEV_ALLOC(v.st_mine, NE * W); DEV_ALLOC(v.st_theirs, NE * W);
-    DEV_ALLOC(v.n_blk, N); DEV_ALLOC(v.root, N); DEV_ALLOC(v.next_root, N);
-    HIP_TRY(hipMemset(v.root, 0, (size_t)N * sizeof(int32_t)));
-    HIP_TRY(hipMemset(v.next_root, 0xff, (size_t)N * sizeof(int32_t)));
-    DEV_ALLOC(v.path, (size_t)N * v.D); DEV_ALLOC(v.path_len, N); DEV_ALLOC(v.leaf_node, N);
-    DEV_ALLOC(v.leaf_mine, (size_t)N * W); DEV_ALLOC(v.leaf_theirs, (size_t)N * W); DEV_ALLOC(v.pending, N);
-    DEV_ALLOC(v.leaf_slot, N); DEV_ALLOC(v.n_leaf, MAX_GROUPS * 2); DEV_ALLOC(v.leaf_index, N);
+    {
+        int32_t blk = 0, slot = 0, dcap = 0;
+        tree_geometry(c.game, &blk, &slot, &dcap);
+        v.rec_block = blk;
+        v.rec_slot = (int64_t)v.E * blk;
+        v.slot_bytes = slot;
+        v.D = dcap;
+        e->leaf_off = 3 * 16;                      // SlotHead is three 16-byte chunks (azsp_internal.h)
+    }
+    DEV_ALLOC(v.rec, (size_t)N * (size_t)v.rec_slot);
+    DEV_ALLOC(v.slot, (size_t)N * v.slot_bytes);
+    HIP_TRY(hipMemset(v.rec, 0, (size_t)N * (size_t)v.rec_slot));
+    HIP_TRY(hipMemset(v.slot, 0, (size_t)N * v.slot_bytes));
+    DEV_ALLOC(v.root_prior, (size_t)N * A);
+    DEV_ALLOC(v.leaf_slot, N); DEV_ALLOC(v.n_leaf, MAX_GROUPS * 2);
     v.nl = v.n_leaf;
     v.nl_other = v.n_leaf + 1;
-    HIP_TRY(hipMemset(v.leaf_index, 0, (size_t)N * sizeof(int32_t)));
     HIP_TRY(hipMemset(v.leaf_slot, 0, (size_t)N * sizeof(int32_t)));
     HIP_TRY(hipMemset(v.n_leaf, 0, MAX_GROUPS * 2 * sizeof(int32_t)));
     DEV_ALLOC(v.eval_p, (size_t)N * AP); DEV_ALLOC(v.eval_v, N);
+    DEV_ALLOC(e->d_stage_p, (size_t)N * AP); DEV_ALLOC(e->d_stage_v, N);
     e->tab_len = v.reuse ? (S + 1) * gi.max_plies + 2 : S + 2;    // largest N_parent + 1 a search can see
     DEV_ALLOC(e->d_sqrt, e->tab_len); DEV_ALLOC(e->d_ctab, e->tab_len); DEV_ALLOC(e->d_expl, e->tab_len);
     v.sqrt_tab = e->d_sqrt;
     v.c_tab = e->d_ctab;
     v.expl_tab = e->d_expl;
+    v.tab_len = e->tab_len;
+    v.tab_lds = e->tab_len < 2048 ? e->tab_len : 2048;     // leading entries staged in LDS by the tree kernels (<= 32 KB)
     v.rules = c.search_rules;
     v.wsum_d = nullptr;
     if (c.search_rules != AZSP_RULES_SIMPLE) {
+        const size_t NC = (size_t)N * v.C;
         DEV_ALLOC(v.wsum_d, NC);
         HIP_TRY(hipMemset(v.wsum_d, 0, NC * sizeof(double)));
     }
@@ -490,10 +502,6 @@ static int create_impl(azsp_engine *e) {
 
     { int rc = upload_exploration_tables(e); if (rc) return rc; }
     HIP_TRY(hipMemset(v.counters, 0, 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(v.kids, 0, NC * sizeof(int32_t)));
-    HIP_TRY(hipMemset(v.prior, 0, NC * sizeof(double)));
-    HIP_TRY(hipMemset(v.cnt, 0, NC * sizeof(int32_t)));
-    HIP_TRY(hipMemset(v.wsum, 0, NC * sizeof(float)));
     HIP_TRY(hipHostMalloc((void **)&e->h_res, sizeof(PlyResultDev), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&e->h_nleaf, 64, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&e->h_counters, 64, hipHostMallocDefault));

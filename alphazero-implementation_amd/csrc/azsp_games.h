@@ -44,6 +44,12 @@ AZ_HD Board<W> board_load(const u64 *arr, size_t idx) {
     return b;
 }
 template <int W>
+AZ_HD Board<W> board_load_strided(const u64 *arr, size_t idx, size_t stride) {      // W words at arr + idx * stride
+    Board<W> b;
+    for (int i = 0; i < W; ++i) b.w[i] = arr[idx * stride + i];
+    return b;
+}
+template <int W>
 AZ_HD void board_store(u64 *arr, size_t idx, const Board<W> &b) {
     for (int i = 0; i < W; ++i) arr[idx * W + i] = b.w[i];
 }

@@ -9,13 +9,52 @@ namespace azsp {
 
 constexpr int MAX_GROUPS = 8; // slot groups searched concurrently on separate HIP streams
 
-// Device-resident state of one engine.  Structure-of-arrays; every per-node array is [slot][C].
-//
-//   node 0            root (of a fresh tree; with tree reuse root[slot] walks down the same arrays)
-//   node 1 + e*A + a  child for action a of the e-th expanded node of this tree ("block" e);
-//                     blocks are bump-allocated in expansion order (deterministic).
-//   kids[x]           first child of x (1 + e*A), 0 while x is unexpanded
-//   blk_parent[e]     the node whose children are block e;  st_*[e] = its canonical position
+// ------------------------------------------------------------------------------------------------
+// Search tree in HBM: one record per EXPANDED node ("block"), holding all its children.
+// ------------------------------------------------------------------------------------------------
+// A descent touches one record per level, so a record is one aligned unit that the lanes of a game fetch with a single
+// 16-byte load each: A child chunks {N, W, first-child block, prior} + one header chunk, padded to a multiple of 128
+// bytes (Connect-4: 7 x 16 + 16 = 128 B = exactly one cache line per level; Gomoku 9x9: 82 x 16 -> 1408 B).
+//   * N  visit_count, W value_sum (float32: numpy-2 semantics; the float64 rule sets keep W in the side array wsum_d)
+//   * kid  0 while the child is unexpanded, else 1 + index of the block holding ITS children
+//   * prior: the reference's float64 prior is f64(p32 * mask) / f64 sum (monte_carlo_tree_search.py:119-121); the record
+//     keeps the float32 numerator per child and the float64 sum once per block and every visit redoes the (IEEE,
+//     deterministic) division -- 4 bytes per child instead of 8 and nothing lost.  Rule set 1 uses the model's float32
+//     as it comes (sum = 1, -1 marks "no child").  Root noise (an option beyond the reference) replaces the root's priors
+//     by float64 values in the side array root_prior (flags bit 0 of the root's block header).
+//   * node ids (path entries, leaf_node, root): 0 = the root of a fresh tree (its own N / W live in the slot record),
+//     1 + e * A + a = child a of block e.  Blocks are bump-allocated in expansion order (deterministic).
+//   * positions are not stored: the descent replays the moves from the slot's current position (G::play per level).
+struct alignas(16) NodeChunk { int32_t n; float w; int32_t kid; float p; };
+struct alignas(16) BlockHead { double psum; int32_t flags; int32_t parent; };
+
+// Per-slot search state, one aligned record per slot (read with one or two 16-byte loads per lane at kernel start):
+//   chunk 0  pending (leaf awaits evaluation), path_len (0 for a root expansion: no backup), leaf_node, n_blk
+//   chunk 1  root (node id of the current root; 0 unless the tree is being reused), root_kid (fresh root: 1 + block of its
+//            children, 0 = unexpanded), root_n / root_w (N and W of a fresh root)
+//   chunk 2  next_root (tree reuse: child chosen by k_finish, or -1), padding
+//   then     leaf position u64 mine[W], theirs[W]; then int32 path[MAX_PLIES + 2] (root .. leaf of the current descent)
+struct alignas(16) SlotHead {
+    int32_t pending, path_len, leaf_node, n_blk;
+    int32_t root, root_kid, root_n;
+    float root_w;
+    int32_t next_root, pad0, pad1, pad2;
+};
+template <class G>
+struct TreeGeo {
+    static constexpr int A = G::A, LPG = G::LPG, APL = G::APL;
+    static constexpr int BLOCK_BYTES = ((A + 1) * 16 + 127) & ~127;
+    static constexpr int HEAD_CHUNKS = 3;                                  // SlotHead
+    static constexpr int LEAF_CHUNK = HEAD_CHUNKS;                         // first chunk of the leaf position
+    static constexpr int PATH_CHUNK = HEAD_CHUNKS + G::W;                  // first chunk of the path (2 u64 per chunk: mine | theirs per word pair)
+    static constexpr int D = G::MAX_PLIES + 2;                             // path capacity
+    static constexpr int SLOT_BYTES = (PATH_CHUNK * 16 + D * 4 + 127) & ~127;
+    static constexpr int SLOT_CHUNKS = SLOT_BYTES / 16;
+    static constexpr int CPL = (SLOT_CHUNKS + LPG - 1) / LPG;              // slot chunks per lane
+    static_assert(APL * LPG >= A + 1, "a block (children + header) must be covered by APL 16-byte loads per lane");
+};
+
+// Device-resident state of one engine.
 struct View {
     int32_t lo;        // first slot of the group this launch works on (groups run on separate streams)
     int32_t grp;       // group index: selects n_leaf[grp]
@@ -23,42 +62,35 @@ struct View {
     int32_t n_slots;
     int32_t cap_eps;   // episode capacity of the arena (>= n_slots)
     int32_t A;         // actions
-    int32_t C;         // node capacity per tree (array stride)
-    int32_t E;         // block capacity per tree = n_sims + 1
-    int32_t D;         // path stride
+    int32_t C;         // node-id capacity per tree (stride of the wsum_d side array)
+    int32_t E;         // block capacity per tree = n_sims + 1 (a whole game's worth with tree reuse)
+    int32_t D;         // path capacity = MAX_PLIES + 2
     int32_t n_sims;
     int32_t max_plies; // history capacity per slot
     int32_t cells;
     int32_t rules;     // AZSP_RULES_*: which of the reference's two search rule sets the kernels follow
     int32_t reuse;     // AZSP_FLAG_TREE_REUSE: the chosen child's subtree becomes the next ply's tree
 
-    // search tree (SoA)
-    int32_t *cnt;       // N  visit_count                       [n_slots][C]
-    float   *wsum;      // W  value_sum (float32, numpy-2 semantics)              rule set 0
-    double  *wsum_d;    // W  value_sum (Python float)                           rule set 1 (else nullptr)
-    double  *prior;     // P  prior (float64; 0 = no child, monte_carlo_tree_search.py:87)
-    int32_t *kids;      // first-child index
-    int32_t *blk_parent;    // [n_slots][E]
-    u64     *st_mine, *st_theirs;   // [n_slots][E][W]   (W = 64-bit words per side, from the game trait)
-    int32_t *n_blk;         // [n_slots]
-    int32_t *root;          // [n_slots] node index of the current root (0 unless the tree is being reused)
-    int32_t *next_root;     // [n_slots] child chosen by k_finish, or -1: the next search starts a fresh tree
-    // per-round scratch
-    int32_t *path;          // [n_slots][D]  root .. leaf of the current descent
-    int32_t *path_len;      // [n_slots]     0 for a root expansion (no backup)
-    int32_t *leaf_node;     // [n_slots]
-    u64     *leaf_mine, *leaf_theirs;   // [n_slots][W] canonical position at the leaf
-    uint8_t *pending;       // [n_slots] leaf awaits evaluation
-    int32_t *leaf_slot;     // [n_slots] per group, at offset lo: compacted (slot order) list of pending slots
+    // search tree
+    uint8_t *rec;           // [n_slots][E] blocks of rec_block bytes (TreeGeo<G>::BLOCK_BYTES)
+    int64_t  rec_slot;      // bytes per slot = E * rec_block
+    int32_t  rec_block;
+    int32_t  slot_bytes;    // TreeGeo<G>::SLOT_BYTES
+    uint8_t *slot;          // [n_slots] slot records
+    double  *wsum_d;        // W as float64 by node id [n_slots][C]: rule sets 1 and 2 (else nullptr)
+    double  *root_prior;    // [n_slots][A] float64 root priors when root noise was mixed in
+    // per-round lists
+    int32_t *leaf_slot;     // [n_slots] per group, at offset lo: list of the slots whose leaf awaits evaluation
     int32_t *n_leaf;        // [MAX_GROUPS][2] leaf counters (two per group: the fused tree kernel alternates them)
     int32_t *nl;            // the counter this launch reads / fills: n_leaf + grp * 2 + parity
     int32_t *nl_other;      // the group's other counter (the fused kernel zeroes it for the round after)
-    int32_t *leaf_index;    // [n_slots] compacted index (absolute, lo-based) of the slot's pending leaf
-    float   *eval_p;        // [n_slots][AP] evaluator output (AP = A padded to 8), at offset lo, indexed by compacted leaf
+    float   *eval_p;        // [n_slots][AP] evaluator output, indexed by SLOT (AP = A padded to 8)
     float   *eval_v;        // [n_slots]
-    const double *sqrt_tab; // [n_sims + 2, or a whole game's simulations with tree reuse] host-computed sqrt(N): bit-identical to math.sqrt
-    const double *c_tab;    // [n_sims + 2] exploration factor c(N): 1.0 unless options say otherwise
-    const double *expl_tab; // [n_sims + 2] c(N) * sqrt(N)  (== sqrt_tab bit for bit while c == 1)
+    const double *sqrt_tab; // [tab_len] host-computed sqrt(N): bit-identical to math.sqrt
+    const double *c_tab;    // [tab_len] exploration factor c(N): 1.0 unless options say otherwise
+    const double *expl_tab; // [tab_len] c(N) * sqrt(N)  (== sqrt_tab bit for bit while c == 1)
+    int32_t tab_len;        // n_sims + 2, or a whole game's simulations with tree reuse
+    int32_t tab_lds;        // how many leading entries the tree kernels stage in LDS
     // search options beyond the reference (all off by default)
     const double *root_noise;   // [n_slots][A] or nullptr
     double  noise_eps, noise_keep;   // eps and (1 - eps), both computed on the host
@@ -94,6 +126,7 @@ struct PlyResultDev {   // mirrors azsp_ply_result; written by k_emit_scan into 
 };
 
 // launchers (azsp_tree.hip)
+void tree_geometry(int game, int32_t *block_bytes, int32_t *slot_bytes, int32_t *path_cap);
 void launch_root_prepare(int game, const View &v, hipStream_t s);
 void launch_select(int game, const View &v, hipStream_t s);
 void launch_compact(const View &v, hipStream_t s);
@@ -101,6 +134,7 @@ void launch_eval_hash(int game, const View &v, uint64_t salt, hipStream_t s);
 void launch_expand(int game, const View &v, hipStream_t s);
 void launch_expand_select(int game, const View &v, hipStream_t s);      // expand of round r-1 fused with select of round r
 void launch_leaf_cells(int game, const View &v, int8_t *dst, hipStream_t s);
+void launch_scatter_eval(int game, const View &v, const float *p_compact, const float *v_compact, hipStream_t s);   // host evaluator: compact order -> slot order
 void launch_finish(int game, const View &v, const double *uniforms, hipStream_t s);
 void launch_count_done(const View &v, int32_t *out, hipStream_t s);
 void launch_emit(int game, const View &v, PlyResultDev *host_result, long long cap, hipStream_t s);
@@ -120,8 +154,9 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split);
 void resnet_destroy(ResNetDev *);
 int resnet_load(ResNetDev *, const float *blob, size_t n_floats, hipStream_t s);   // 0 ok
 size_t resnet_blob_floats(int game, int blocks, int channels);
-// evaluates boards leaf_mine/theirs[leaf_slot[j]] for j < *n_leaf (<= max_leaves) into out_p/out_v
-void resnet_forward(ResNetDev *, int game, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot,
+// evaluates the leaf positions of the slots leaf_slot[j], j < *n_leaf (<= max_leaves), into out_p[slot][AP] / out_v[slot];
+// the position of slot g: mine = leaf0 + g * board_stride (W words), theirs = the W words after it
+void resnet_forward(ResNetDev *, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot,
                     const int32_t *n_leaf, int max_leaves, float *out_p, float *out_v, hipStream_t s);
 double resnet_flops_per_board(const ResNetDev *);
 // diagnostics: arm the stamped instantiation for this thread's next fp32 launch; read back its clock / span
@@ -133,7 +168,7 @@ struct ResNet16Dev;
 ResNet16Dev *resnet16_create(int game, int blocks, int channels);
 void resnet16_destroy(ResNet16Dev *);
 int resnet16_load(ResNet16Dev *, const float *blob, size_t n_floats, hipStream_t s);
-void resnet16_forward(ResNet16Dev *, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
+void resnet16_forward(ResNet16Dev *, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
                       int max_leaves, float *out_p, float *out_v, hipStream_t s);
 
 }  // namespace azsp

@@ -103,6 +103,7 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
     n->g = g;
     n->game = game;
     n->forced_variant = resnet_forced_variant(game, g.NT);
+    n->g_words = game == 2 ? Gomoku9::W : Connect4::W;
     size_t off = 0;
     auto reserve = [&](size_t cnt) { size_t o = off; off += (cnt + 3) & ~(size_t)3; return o; };
     n->o_stem_w = reserve((size_t)14 * 64 * g.NT);
@@ -323,9 +324,9 @@ int resnet_forced_variant(int game, int nt) {
     return -1;
 }
 
-void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
+void resnet_forward(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
                     int max_leaves, float *out_p, float *out_v, hipStream_t s) {
-    if (n->f16) { resnet16_forward(n->f16, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }
+    if (n->f16) { resnet16_forward(n->f16, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }
     const Variant *v = pick_variant(n, game, max_leaves);
     if (!v) return;                        // resnet_create refused every geometry without a variant
     FwdArgs a;
@@ -343,7 +344,7 @@ void resnet_forward(ResNetDev *n, int game, const u64 *mine, const u64 *theirs, 
     P.dbg = nullptr;
     P.perm = n->d_perm ? n->d_perm + v->perm_offset : nullptr;
     P.conv_w4 = n->has_w4 ? d + n->o_conv_w4 : nullptr;
-    a.mine = mine; a.theirs = theirs; a.leaf_slot = leaf_slot; a.n_leaf = n_leaf; a.max_leaves = max_leaves;
+    a.mine = leaf0; a.theirs = leaf0 + n->g_words; a.bstride = board_stride; a.leaf_slot = leaf_slot; a.n_leaf = n_leaf; a.max_leaves = max_leaves;
     a.out_p = out_p; a.out_v = out_v; a.s = s;
     v->launch(a);
 }

@@ -176,7 +176,7 @@ __device__ __forceinline__ void conv16s(f32x16 (&acc)[NTILE], const h8 *__restri
 
 template <class G, int CT, int WR, int ABL = 0>
 __global__ __launch_bounds__(64 * WR * CT, 2)
-void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
+void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs, int bstride,
                           const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
                           float *__restrict__ out_p, float *__restrict__ out_v) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
@@ -269,7 +269,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
                 const int r = s_perm[wr * (MT * 32) + mt * 32 + r32];
                 const int b = r / CELLS, pos = r % CELLS, y = pos / COLS, x = pos % COLS;
                 u64 bm = 0, bt = 0;
-                if (r < TB * CELLS && board0 + b < n_leaf) { const int slot = leaf_slot[board0 + b]; bm = mine[slot]; bt = theirs[slot]; }
+                if (r < TB * CELLS && board0 + b < n_leaf) { const int slot = leaf_slot[board0 + b]; bm = mine[(size_t)slot * bstride]; bt = theirs[(size_t)slot * bstride]; }
                 h8 ah;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -384,7 +384,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     if (tid < TB && board0 + tid < n_leaf) {
         const int j = board0 + tid;
         const int slot = leaf_slot[j];
-        const uint32_t legal = G::legal_mask(mine[slot], theirs[slot]);
+        const uint32_t legal = G::legal_mask(mine[(size_t)slot * bstride], theirs[(size_t)slot * bstride]);
         float mx = -INFINITY;
 #pragma unroll
         for (int a = 0; a < A; ++a) if ((legal >> a) & 1u) mx = fmaxf(mx, logits[tid * 8 + a]);
@@ -392,8 +392,8 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
 #pragma unroll
         for (int a = 0; a < A; ++a) { ex[a] = ((legal >> a) & 1u) ? expf(logits[tid * 8 + a] - mx) : 0.0f; den += ex[a]; }
 #pragma unroll
-        for (int a = 0; a < Connect4::AP; ++a) out_p[(size_t)j * Connect4::AP + a] = a < A ? ex[a < A ? a : 0] / den : 0.0f;
-        out_v[j] = tanhf(logits[tid * 8 + 7]);
+        for (int a = 0; a < Connect4::AP; ++a) out_p[(size_t)slot * Connect4::AP + a] = a < A ? ex[a < A ? a : 0] / den : 0.0f;
+        out_v[slot] = tanhf(logits[tid * 8 + 7]);
     }
     STAMP16(55);
 }
@@ -575,7 +575,7 @@ int resnet16_load(ResNet16Dev *n, const float *blob, size_t n_floats, hipStream_
 }
 
 template <int CT, int WR, int ABL = 0>
-static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
+static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, int bstride, const int32_t *leaf_slot, const int32_t *n_leaf,
                      int max_leaves, float *out_p, float *out_v, hipStream_t s) {
     using G = Connect4;
     constexpr int WAVES = WR * CT, RS = 32 * CT + 8, TB = F16_ROWS / G::CELLS;
@@ -593,11 +593,12 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, c
     const int grid = (max_leaves + TB - 1) / TB;
     Net16Params Q = P;
     Q.perm = P.perm + (size_t)(WR == 1 ? 0 : WR == 2 ? 1 : WR == 4 ? 2 : 3) * F16_ROWS;      // row order of this wave grid
-    hipLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR, ABL>), dim3(grid), dim3(64 * WAVES), lds, s, Q, mine, theirs, leaf_slot, n_leaf, out_p, out_v);
+    hipLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR, ABL>), dim3(grid), dim3(64 * WAVES), lds, s, Q, mine, theirs, bstride, leaf_slot, n_leaf, out_p, out_v);
 }
 
-void resnet16_forward(ResNet16Dev *n, const u64 *mine, const u64 *theirs, const int32_t *leaf_slot, const int32_t *n_leaf,
+void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32_t *leaf_slot, const int32_t *n_leaf,
                       int max_leaves, float *out_p, float *out_v, hipStream_t s) {
+    const u64 *mine = leaf0, *theirs = leaf0 + Connect4::W;
     Net16Params P;
     unsigned char *d = n->d_blob;
     auto H = [&](size_t o) { return reinterpret_cast<const h8 *>(d + o); };
@@ -612,7 +613,7 @@ void resnet16_forward(ResNet16Dev *n, const u64 *mine, const u64 *theirs, const 
     P.dbg = nullptr;
     // wave grid WR x CT over the 256-row x C tile (tuning knob AZSP_F16_WR; results do not depend on it)
     static const int wr_env = [] { const char *e = getenv("AZSP_F16_WR"); return e ? atoi(e) : 0; }();
-#define L16(CTV, WRV) launch16<CTV, WRV>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
+#define L16(CTV, WRV) launch16<CTV, WRV>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
     switch (n->CT) {
         case 1: if (wr_env == 8 || (!wr_env && max_leaves <= 768)) L16(1, 8); else L16(1, 4); break;
         case 2: {
@@ -626,7 +627,7 @@ void resnet16_forward(ResNet16Dev *n, const u64 *mine, const u64 *theirs, const 
                     (void)hipMemsetAsync(dd, 0, cnt * 8, s);
                     Net16Params Q = P;
                     Q.dbg = dd;
-                    launch16<2, 2, 8>(Q, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+                    launch16<2, 2, 8>(Q, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
                     (void)hipStreamSynchronize(s);
                     std::vector<unsigned long long> h(cnt);
                     (void)hipMemcpy(h.data(), dd, cnt * 8, hipMemcpyDeviceToHost);
@@ -656,10 +657,10 @@ void resnet16_forward(ResNet16Dev *n, const u64 *mine, const u64 *theirs, const 
             }
             static const int abl = [] { const char *e = getenv("AZSP_F16_ABLATE"); return e ? atoi(e) : 0; }();
             if (abl) {   // timing-only diagnostic builds (wrong results): 1 = no weight streaming, 2 = no LDS fragment traffic, 4 = no activation stores
-                if (abl == 1) launch16<2, 2, 1>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
-                else if (abl == 2) launch16<2, 2, 2>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
-                else if (abl == 3) launch16<2, 2, 3>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
-                else launch16<2, 2, 4>(P, mine, theirs, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+                if (abl == 1) launch16<2, 2, 1>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+                else if (abl == 2) launch16<2, 2, 2>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+                else if (abl == 3) launch16<2, 2, 3>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+                else launch16<2, 2, 4>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
                 break;
             }
             if (wr_env == 4 || (!wr_env && max_leaves <= 768)) L16(2, 4); else L16(2, 2);   // small batch: more waves per board

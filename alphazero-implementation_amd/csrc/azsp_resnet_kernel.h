@@ -64,6 +64,7 @@ struct ResNetDev {
     int32_t *d_perm = nullptr;    // [2][256] row orders of the tap-skipping Connect-4 kernels: 4x1 and 2x2 wave grids
     size_t o_conv_w4 = 0;         // quad-k-step copy of the conv weights (64-channel Connect-4 nets)
     bool has_w4 = false;
+    int g_words = 1;              // 64-bit words per side of a position (game trait W)
     int forced_variant = -1;      // index into the variant table if AZSP_RESNET_VARIANT named one at creation, else -1
 };
 
@@ -422,7 +423,7 @@ __device__ __forceinline__ void tower_layer(f32x16 (&acc)[4][1], const float *ac
 __device__ __forceinline__ int cd_row(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
 
 template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4, bool TR = false>
-__global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 && NT <= 2 ? 3 : (RW * CW == 16 ? 1 : (RW * CW > 8 ? RW * CW / 4 : (RW * CW == 8 && RW * MT == 8 ? 1 : 2))))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs,
+__global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 && NT <= 2 ? 3 : (RW * CW == 16 ? 1 : (RW * CW > 8 ? RW * CW / 4 : (RW * CW == 8 && RW * MT == 8 ? 1 : 2))))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs, int bstride,
                                                          const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
                                                          float *__restrict__ out_p, float *__restrict__ out_v) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
@@ -491,8 +492,8 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
         bt[mt] = board_zero<G::W>();
         if (real) {
             const int slot = leaf_slot[board0 + b];
-            bm[mt] = board_load<G::W>(mine, slot);
-            bt[mt] = board_load<G::W>(theirs, slot);
+            bm[mt] = board_load_strided<G::W>(mine, slot, bstride);
+            bt[mt] = board_load_strided<G::W>(theirs, slot, bstride);
         }
     }
 
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     if (tid < TB && board0 + tid < n_leaf) {
         const int j = board0 + tid;
         const int slot = leaf_slot[j];
-        const typename G::B bmine = board_load<G::W>(mine, slot), btheirs = board_load<G::W>(theirs, slot);
+        const typename G::B bmine = board_load_strided<G::W>(mine, slot, bstride), btheirs = board_load_strided<G::W>(theirs, slot, bstride);
         const float *lg = logits + tid * AP;
         float mx = -INFINITY;
 #pragma unroll 1
@@ -823,8 +824,8 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
         for (int a = 0; a < A; ++a) den += G::legal(bmine, btheirs, a) ? expf(lg[a] - mx) : 0.0f;
 #pragma unroll 1
         for (int a = 0; a < AP; ++a)
-            out_p[(size_t)j * AP + a] = (a < A && G::legal(bmine, btheirs, a)) ? expf(lg[a] - mx) / den : 0.0f;
-        out_v[j] = tanhf(vlogit ? vlogit[tid] : lg[7]);
+            out_p[(size_t)slot * AP + a] = (a < A && G::legal(bmine, btheirs, a)) ? expf(lg[a] - mx) / den : 0.0f;     // results by slot
+        out_v[slot] = tanhf(vlogit ? vlogit[tid] : lg[7]);
     }
     STAMP(55);
 }
@@ -834,8 +835,9 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
 // ------------------------------------------------------------------------------------------------
 struct FwdArgs {
     NetParams P;
-    const u64 *mine, *theirs;
-    const int32_t *leaf_slot, *n_leaf;      // compacted leaf list of the group and its length (device)
+    const u64 *mine, *theirs;               // leaf position of slot g: W words at mine + g * bstride / theirs + g * bstride
+    int bstride;
+    const int32_t *leaf_slot, *n_leaf;      // leaf list of the group (slot ids) and its length (device)
     int max_leaves;
     float *out_p, *out_v;
     hipStream_t s;
@@ -888,12 +890,12 @@ static void launch_forward(const FwdArgs &a) {
         if (resnet_trace_wanted(&print)) {
             trace_forward(a.P, grid, [&](const NetParams &Q) {
                 hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW, true>), dim3(grid), dim3(64 * RW * CW), lds, a.s, Q,
-                                   a.mine, a.theirs, a.leaf_slot, a.n_leaf, a.out_p, a.out_v); }, a.s, print);
+                                   a.mine, a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v); }, a.s, print);
             return;
         }
     }
     hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW>), dim3(grid), dim3(64 * RW * CW), lds, a.s, a.P, a.mine, a.theirs,
-                       a.leaf_slot, a.n_leaf, a.out_p, a.out_v);
+                       a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v);
 }
 
 // One function per compiled kernel variant (azsp_resnet_k*.hip); the table that picks among them is in azsp_resnet.hip.

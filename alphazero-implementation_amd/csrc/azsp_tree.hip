@@ -66,294 +66,172 @@ __device__ __forceinline__ int red_add(int x) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// tree storage access (layout: azsp_internal.h)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t *slot_ptr(const View &v, int g) { return v.slot + (size_t)g * v.slot_bytes; }
+__device__ __forceinline__ uint8_t *block_ptr(const View &v, int g, int e) { return v.rec + (size_t)g * v.rec_slot + (size_t)e * v.rec_block; }
+template <class G>
+__device__ __forceinline__ NodeChunk *node_chunk(const View &v, int g, int node) {      // node >= 1
+    const int e = (node - 1) / G::A, a = (node - 1) % G::A;
+    return reinterpret_cast<NodeChunk *>(block_ptr(v, g, e)) + a;
+}
+__device__ __forceinline__ int comp4(const int4 &t, int k) { return k == 0 ? t.x : (k == 1 ? t.y : (k == 2 ? t.z : t.w)); }
+__device__ __forceinline__ double make_double(int lo, int hi) { return __hiloint2double(hi, lo); }
+
+// The slot record of game g in registers: every lane of the game's group loads the 16-byte chunks lane, lane + LPG, ...;
+// the scalar fields are then broadcast from the lanes that hold them.  `sc` keeps the raw chunks (the path lives there).
+template <class G>
+struct SlotRegs {
+    int pending, path_len, leaf_node, n_blk, root, root_kid, root_n, next_root;
+    float root_w;
+    typename G::B lm, lt;                       // leaf position
+    int4 sc[TreeGeo<G>::CPL];
+};
+template <class G>
+__device__ __forceinline__ int4 slot_chunk_bcast(const SlotRegs<G> &st, int c) {         // c: compile-time chunk index
+    constexpr int LPG = G::LPG;
+    int4 r;
+    const int4 &src = st.sc[c / LPG];
+    r.x = __shfl(src.x, c % LPG, LPG); r.y = __shfl(src.y, c % LPG, LPG);
+    r.z = __shfl(src.z, c % LPG, LPG); r.w = __shfl(src.w, c % LPG, LPG);
+    return r;
+}
+template <class G>
+__device__ __forceinline__ void slot_load(const View &v, int g, int lane, bool live, SlotRegs<G> &st) {
+    using T = TreeGeo<G>;
+    const int4 *src = reinterpret_cast<const int4 *>(slot_ptr(v, g));
+#pragma unroll
+    for (int k = 0; k < T::CPL; ++k) {
+        const int c = lane + k * G::LPG;
+        st.sc[k] = (live && c < T::SLOT_CHUNKS) ? src[c] : make_int4(0, 0, 0, 0);
+    }
+    const int4 c0 = slot_chunk_bcast<G>(st, 0), c1 = slot_chunk_bcast<G>(st, 1), c2 = slot_chunk_bcast<G>(st, 2);
+    st.pending = c0.x; st.path_len = c0.y; st.leaf_node = c0.z; st.n_blk = c0.w;
+    st.root = c1.x; st.root_kid = c1.y; st.root_n = c1.z; st.root_w = __int_as_float(c1.w);
+    st.next_root = c2.x;
+    if constexpr (G::W == 1) {
+        const int4 b = slot_chunk_bcast<G>(st, T::LEAF_CHUNK);
+        st.lm.w[0] = (u64)(uint32_t)b.x | ((u64)(uint32_t)b.y << 32);
+        st.lt.w[0] = (u64)(uint32_t)b.z | ((u64)(uint32_t)b.w << 32);
+    } else {
+        const int4 bm = slot_chunk_bcast<G>(st, T::LEAF_CHUNK), bt = slot_chunk_bcast<G>(st, T::LEAF_CHUNK + 1);
+        st.lm.w[0] = (u64)(uint32_t)bm.x | ((u64)(uint32_t)bm.y << 32); st.lm.w[1] = (u64)(uint32_t)bm.z | ((u64)(uint32_t)bm.w << 32);
+        st.lt.w[0] = (u64)(uint32_t)bt.x | ((u64)(uint32_t)bt.y << 32); st.lt.w[1] = (u64)(uint32_t)bt.z | ((u64)(uint32_t)bt.w << 32);
+    }
+}
+// path entry i (< D) of the loaded slot record, for the lane that holds it: chunk PATH_CHUNK + i / 4, component i % 4
+template <class G>
+__device__ __forceinline__ bool path_entry_here(int lane, int k, int j, int &i) {        // chunk lane + k * LPG, component j
+    using T = TreeGeo<G>;
+    const int c = lane + k * G::LPG;
+    i = 4 * (c - T::PATH_CHUNK) + j;
+    return c >= T::PATH_CHUNK && c < T::SLOT_CHUNKS && i < T::D;
+}
+// write the head chunks back (lane 0) -- the fields a kernel changed
+template <class G>
+__device__ __forceinline__ void slot_store_head(const View &v, int g, const SlotRegs<G> &st) {
+    int4 *dst = reinterpret_cast<int4 *>(slot_ptr(v, g));
+    dst[0] = make_int4(st.pending, st.path_len, st.leaf_node, st.n_blk);
+    dst[1] = make_int4(st.root, st.root_kid, st.root_n, __float_as_int(st.root_w));
+    dst[2] = make_int4(st.next_root, 0, 0, 0);
+}
+template <class G>
+__device__ __forceinline__ void slot_store_leaf(const View &v, int g, const typename G::B &m, const typename G::B &t) {
+    u64 *dst = reinterpret_cast<u64 *>(slot_ptr(v, g) + TreeGeo<G>::LEAF_CHUNK * 16);
+#pragma unroll
+    for (int i = 0; i < G::W; ++i) { dst[i] = m.w[i]; dst[G::W + i] = t.w[i]; }
+}
+
+// exploration tables: the leading tab_lds entries sit in LDS (a table lookup would otherwise be one more dependent
+// global round trip per tree level)
+struct Tabs { const double *expl, *sqrt_, *c; };
+template <int R>
+__device__ __forceinline__ void stage_tabs(const View &v, double *s_tab, Tabs &t) {
+    const int n = v.tab_lds;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        if constexpr (R != 1) s_tab[i] = v.expl_tab[i];
+        else { s_tab[i] = v.sqrt_tab[i]; s_tab[n + i] = v.c_tab[i]; }
+    }
+    t.expl = s_tab; t.sqrt_ = s_tab; t.c = s_tab + n;
+}
+__device__ __forceinline__ double tab_at(const double *lds, const double *glob, int n_lds, int i) { return i < n_lds ? lds[i] : glob[i]; }
+
+// ------------------------------------------------------------------------------------------------
 // root preparation: fresh tree per slot, root queued for evaluation (no backup: path_len = 0)
 // ------------------------------------------------------------------------------------------------
 template <class G, int R>
 __global__ void k_root_prepare(View v) {
+    using T = TreeGeo<G>;
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g == 0) v.nl_other[0] = 0;             // the first fused expand+select round appends to the other counter
     if (g >= v.n_act) return;
     g += v.lo;
-    size_t base = (size_t)g * v.C;
+    SlotHead *h = reinterpret_cast<SlotHead *>(slot_ptr(v, g));
     int root = 0;
     if (v.reuse) {
         // tree reuse (not in the reference, which rebuilds its trees every ply): the child chosen by the last
         // k_finish becomes the root with everything below it; blocks keep being bump-allocated after the old ones
-        const int nr = v.next_root[g];
-        v.next_root[g] = -1;
+        const int nr = h->next_root;
+        h->next_root = -1;
         if (nr > 0) {
-            v.root[g] = nr;
-            if (v.kids[base + nr] != 0) { v.pending[g] = 0; return; }      // expanded: nothing to evaluate
-            root = nr;                                                      // never visited: expand it as a root
+            h->root = nr;
+            if (node_chunk<G>(v, g, nr)->kid != 0) { h->pending = 0; return; }      // expanded: nothing to evaluate
+            root = nr;                                                                // never visited: expand it as a root
         } else {
-            v.n_blk[g] = 0;
-            v.root[g] = 0;
+            h->n_blk = 0;
+            h->root = 0;
         }
     } else {
-        v.n_blk[g] = 0;
+        h->n_blk = 0;
+        h->root = 0;
     }
-    v.cnt[base + root] = 0;
-    if constexpr (R == 0) v.wsum[base + root] = 0.0f; else v.wsum_d[base + root] = 0.0;
-    v.kids[base + root] = 0;
-    if constexpr (R != 1) v.path_len[g] = 0;       // run_batch :112-123: the root value is discarded
-    else { v.path_len[g] = 1; v.path[(size_t)g * v.D] = root; }   // search.py:72-91: expanding the root IS simulation 1
-    v.leaf_node[g] = root;
-    board_store<G::W>(v.leaf_mine, g, board_load<G::W>(v.cur_mine, g));
-    board_store<G::W>(v.leaf_theirs, g, board_load<G::W>(v.cur_theirs, g));
-    v.pending[g] = 1;
+    if (root == 0) {
+        h->root_kid = 0;
+        h->root_n = 0;
+        h->root_w = 0.0f;
+    } else {
+        NodeChunk *c = node_chunk<G>(v, g, root);
+        c->n = 0;
+        c->w = 0.0f;
+        c->kid = 0;
+    }
+    if constexpr (R != 0) v.wsum_d[(size_t)g * v.C + root] = 0.0;
+    int32_t *path = reinterpret_cast<int32_t *>(slot_ptr(v, g) + T::PATH_CHUNK * 16);
+    if constexpr (R != 1) h->path_len = 0;         // run_batch :112-123: the root value is discarded
+    else { h->path_len = 1; path[0] = root; }      // search.py:72-91: expanding the root IS simulation 1
+    h->leaf_node = root;
+    slot_store_leaf<G>(v, g, board_load<G::W>(v.cur_mine, g), board_load<G::W>(v.cur_theirs, g));
+    h->pending = 1;
 }
 
 // ------------------------------------------------------------------------------------------------
-// selection: PUCT descent to the first unexpanded node, leaf step, terminal test
+// expansion + backup of an evaluated leaf (Node.expand :80-90, backpropagate :214-223, mask / renormalise :119-121)
 // ------------------------------------------------------------------------------------------------
-// APPEND: the non-terminal leaves are appended to the group's leaf list here (one atomic per wavefront; the order of
-// the list does not matter to the device evaluators, whose outputs do not depend on a position's place in the batch)
-// instead of by the stable k_compact pass that the host-callback evaluator needs.
-template <class G, int R, bool APPEND>
-__device__ __forceinline__ void select_body(const View &v, int *s_path) {
-    using WT = typename std::conditional<R == 0, float, double>::type;
-    const WT *wsum_r = R == 0 ? (const WT *)v.wsum : (const WT *)v.wsum_d;
-    WT *wsum_w = R == 0 ? (WT *)v.wsum : (WT *)v.wsum_d;
-    constexpr int A = G::A, LPG = G::LPG, APL = G::APL, GPW = 64 / LPG;
-    static_assert(APL * LPG >= A, "every action needs a lane slot");
-    const int lane = threadIdx.x & (LPG - 1);
-    const int grp = threadIdx.x / LPG;
-    const int gl = blockIdx.x * GPW + grp;
-    const bool live = gl < v.n_act;
-    const int g = live ? v.lo + gl : 0;
-    const size_t base = (size_t)g * v.C;
-    int *my_path = s_path + grp * v.D;
-
-    // One dependent round trip per tree level: the lanes fetch N, W, P AND the first-child index of their
-    // children together; the chosen child's first-child index then comes from a shuffle, and below the root
-    // N_parent is not loaded but rebuilt from the children (an expanded node is visited once at expansion and
-    // afterwards only on the way to one of its children: N = 1 + sum N_child).  The root's own count is read
-    // up front, next to its first-child index (no dependency): whether it was counted at its expansion differs
-    // between the rule sets and for a reused subtree.
-    const int root = live ? (v.reuse ? v.root[g] : 0) : 0;
-    int node = root, depth = 0, parent_fc = 0, action = 0;
-    int fc = live ? v.kids[base + root] : 0;
-    const int n_root = live ? v.cnt[base + root] : 0;
-    bool walking = live;
-    while (true) {
-        walking = walking && fc != 0;               // Node.expanded() :35-36
-        if (!__any(walking)) break;
-        double p[APL];
-        int n[APL], kc[APL];
-        WT w[APL];
-        int nsum = 0;
-#pragma unroll
-        for (int k = 0; k < APL; ++k) {
-            const int a = lane + k * LPG;
-            const bool in = walking && a < A;
-            const int child = fc + a;
-            p[k] = in ? v.prior[base + child] : (R != 1 ? 0.0 : -1.0);     // lanes without an action: no child
-            n[k] = in ? v.cnt[base + child] : 0;
-            w[k] = in ? wsum_r[base + child] : (WT)0;
-            kc[k] = in ? v.kids[base + child] : 0;
-            nsum += n[k];
-        }
-        const int nkids = red_add<LPG>(nsum);
-        const int np_ = node == root ? n_root : nkids + 1;
-        double score = -INFINITY;
-        int best = lane;
-#pragma unroll
-        for (int k = 0; k < APL; ++k) {
-            if (child_exists<R>(p[k])) {
-                double q = 0.0, u;
-                if constexpr (R == 0) {
-                    // ucb_score :11-22.  (prior * sqrt(N_parent)) / (n + 1) in float64 [expl_tab = c * sqrt, c = 1
-                    // in the reference]; -(W / n) in float32 (numpy 2.x), promoted for the sum.
-                    u = (p[k] * v.expl_tab[np_]) / (double)(n[k] + 1);
-                    if (n[k] > 0) {
-                        const float qf = w[k] / (float)n[k];
-                        q = (double)(-qf);
-                    }
-                } else if constexpr (R == 2) {
-                    // the same expression as numpy 1.x evaluates it: W is float64 there (legacy scalar promotion
-                    // of `0.0 + np.float32`), so -(W / n) is a float64 division
-                    u = (p[k] * v.expl_tab[np_]) / (double)(n[k] + 1);
-                    if (n[k] > 0) q = -(w[k] / (double)n[k]);
-                } else {
-                    // search.py:33-40: child.value + c * prior * sqrt(N) / (1 + n), left to right, all float64
-                    u = ((v.c_tab[np_] * p[k]) * v.sqrt_tab[np_]) / (double)(1 + n[k]);
-                    if (n[k] > 0) q = w[k] / (double)n[k];
-                }
-                double sc = q + u;
-                if (!(sc == sc)) sc = -INFINITY;    // NaN is never '>' the running best
-                if (sc > score) { score = sc; best = lane + k * LPG; }   // ascending actions within the lane
-            }
-        }
-        // argmax, strict '>' in ascending action order == maximum score, lowest action on ties
-#pragma unroll
-        for (int m = 1; m < LPG; m <<= 1) {
-            const double so = __shfl_xor(score, m, LPG);
-            const int bo = __shfl_xor(best, m, LPG);
-            if (so > score || (so == score && bo < best)) { score = so; best = bo; }
-        }
-        int kc_sel = kc[0];
-#pragma unroll
-        for (int k = 1; k < APL; ++k) if (best / LPG == k) kc_sel = kc[k];
-        const int next_fc = __shfl(kc_sel, best & (LPG - 1), LPG);
-        if (walking) {
-            if (lane == 0) my_path[depth] = node;
-            parent_fc = fc;
-            action = best;
-            node = fc + best;
-            fc = next_fc;
-            ++depth;
-        }
-    }
-    if (live && lane == 0) my_path[depth] = node;
-    const int L = depth + 1;                        // nodes on the path, root .. leaf
-    __syncthreads();                                // one wave per block: orders the LDS path writes
-
-    // leaf step (:135-145): parent's position + action, flip perspective, terminal test
-    int term = TERM_NONE;
-    typename G::B nm = board_zero<G::W>(), nt = board_zero<G::W>();
-    if (live) {
-        const int e = (parent_fc - 1) / A;
-        const typename G::B pm = board_load<G::W>(v.st_mine, (size_t)g * v.E + e);
-        const typename G::B pt = board_load<G::W>(v.st_theirs, (size_t)g * v.E + e);
-        G::play(pm, pt, action, nm, nt);
-        term = G::terminal(nm, nt);
-    }
-    if (live && term != TERM_NONE) {
-        // terminal leaf: never expanded.  Rule set 0: value in {+1,-1,0} for the side to move at the leaf,
-        // backpropagate :214-223 -- the sign alternates with distance from the leaf (to_play alternates level by
-        // level).  Rule set 1 (search.py:78-80,:48-58): the utility of the player who MOVED into the leaf, added
-        // unchanged to the leaf and to its parent (no flip above a terminal node), alternating from there on.
-        const WT val = R != 1 ? (WT)term : (term == 0 ? (WT)0 : (WT)(-term));
-        for (int k = lane; k < L; k += LPG) {
-            const int nd = my_path[L - 1 - k];
-            const bool neg = R != 1 ? (k & 1) : (k > 0 && ((k - 1) & 1));
-            const WT dv = neg ? -val : val;
-            wsum_w[base + nd] = wsum_r[base + nd] + dv;
-            v.cnt[base + nd] = v.cnt[base + nd] + 1;
-        }
-        if (lane == 0) {
-            v.pending[g] = 0;
-            atomicAdd(&v.counters[1], 1ull);
-            atomicAdd(&v.counters[2], (unsigned long long)L);
-        }
-    } else if (live) {
-        for (int k = lane; k < L; k += LPG) v.path[(size_t)g * v.D + k] = my_path[k];
-        if (lane == 0) {
-            v.pending[g] = 1;
-            v.path_len[g] = L;
-            v.leaf_node[g] = node;
-            board_store<G::W>(v.leaf_mine, g, nm);
-            board_store<G::W>(v.leaf_theirs, g, nt);
-            atomicAdd(&v.counters[2], (unsigned long long)L);
-        }
-    }
-    if constexpr (APPEND) {
-        const bool mine_to_add = live && term == TERM_NONE && lane == 0;
-        const unsigned long long bal = __ballot(mine_to_add);
-        const int cnt = __popcll(bal);
-        int base_j = 0;
-        if (cnt > 0) {
-            const int leader = __ffsll((long long)bal) - 1;
-            if ((int)threadIdx.x == leader) {
-                base_j = atomicAdd(v.nl, cnt);
-                atomicAdd(&v.counters[0], (unsigned long long)cnt);
-            }
-            base_j = __shfl(base_j, leader, 64);
-        }
-        if (mine_to_add) {
-            const int j = v.lo + base_j + __popcll(bal & ((1ull << threadIdx.x) - 1ull));
-            v.leaf_slot[j] = g;
-            v.leaf_index[g] = j;
-        }
-    }
-}
-
+// One game per LPG lanes; `st` is the game's slot record (registers, updated here, stored by the caller).
 template <class G, int R>
-__global__ __launch_bounds__(64) void k_select(View v) {
-    extern __shared__ int s_path[];                 // [GPW games][D]
-    select_body<G, R, false>(v, s_path);
-}
-
-// ------------------------------------------------------------------------------------------------
-// stable (slot-order) compaction of the pending leaves; one workgroup
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_compact(View v) {
-    __shared__ int s_sum[1024];
-    const int t = threadIdx.x;
-    const int per = (v.n_act + 1023) / 1024;
-    const int lo = v.lo + t * per, hi = min(lo + per, v.lo + v.n_act);
-    int c = 0;
-    for (int g = lo; g < hi; ++g) c += v.pending[g];
-    s_sum[t] = c;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {      // Hillis-Steele inclusive scan
-        int x = (t >= off) ? s_sum[t - off] : 0;
-        __syncthreads();
-        s_sum[t] += x;
-        __syncthreads();
-    }
-    int pos = v.lo + s_sum[t] - c;
-    for (int g = lo; g < hi; ++g)
-        if (v.pending[g]) { v.leaf_index[g] = pos; v.leaf_slot[pos++] = g; }
-    if (t == 1023) {
-        v.nl[0] = s_sum[1023];
-        atomicAdd(&v.counters[0], (unsigned long long)s_sum[1023]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// hash evaluator
-// ------------------------------------------------------------------------------------------------
-template <class G>
-__global__ void k_eval_hash(View v, uint64_t salt) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= v.nl[0]) return;
-    j += v.lo;
-    const int g = v.leaf_slot[j];
-    const typename G::B m = board_load<G::W>(v.leaf_mine, g), t = board_load<G::W>(v.leaf_theirs, g);
-    float *p = v.eval_p + (size_t)j * G::AP;
-    v.eval_v[j] = hash_eval<G>(m, t, salt, p);
-    for (int a = G::A; a < G::AP; ++a) p[a] = 0.0f;
-}
-
-// ------------------------------------------------------------------------------------------------
-// expansion + backup of the evaluated leaves
-// ------------------------------------------------------------------------------------------------
-// BY_SLOT = false: lane groups are mapped to the compacted leaves j (stand-alone k_expand); true: to the slots of
-// the group, a slot taking part if its last descent left a leaf awaiting expansion (fused expand + select kernel).
-template <class G, int R, bool BY_SLOT>
-__device__ __forceinline__ void expand_body(const View &v, double (*s_pa)[G::AP]) {
-    constexpr int A = G::A, LPG = G::LPG, APL = G::APL, GPW = 64 / LPG;
+__device__ __forceinline__ void expand_game(const View &v, int g, int lane, int grp, bool live, SlotRegs<G> &st,
+                                            double (*s_pa)[G::AP]) {
+    constexpr int A = G::A, LPG = G::LPG, APL = G::APL;
+    using T = TreeGeo<G>;
     using WT = typename std::conditional<R == 0, float, double>::type;
-    WT *wsum = R == 0 ? (WT *)v.wsum : (WT *)v.wsum_d;
-    const int lane = threadIdx.x & (LPG - 1);
-    const int grp = threadIdx.x / LPG;
-    const int jl = blockIdx.x * GPW + grp;
-    bool live;
-    int j, g;
-    if constexpr (BY_SLOT) {
-        g = jl < v.n_act ? v.lo + jl : v.lo;
-        live = jl < v.n_act && v.pending[g] != 0;
-        j = live ? v.leaf_index[g] : v.lo;
-    } else {
-        live = jl < v.nl[0];
-        j = v.lo + (live ? jl : 0);
-        g = v.leaf_slot[j];
-    }
-    const size_t base = (size_t)g * v.C;
-    const typename G::B mine = board_load<G::W>(v.leaf_mine, g), theirs = board_load<G::W>(v.leaf_theirs, g);
 
     // action_probs * valid_moves -> float64 ; /= np.sum(action_probs)
     double pa[APL];
+    float p32[APL];
     bool ok[APL];
 #pragma unroll
     for (int k = 0; k < APL; ++k) {
         const int a = lane + k * LPG;
         pa[k] = 0.0;
-        ok[k] = live && a < A && G::legal(mine, theirs, a);
-        if (live && a < A) pa[k] = (double)v.eval_p[(size_t)j * G::AP + a] * (double)(ok[k] ? 1 : 0);
+        p32[k] = 0.0f;
+        ok[k] = live && a < A && G::legal(st.lm, st.lt, a);
+        if (live && a < A) {
+            p32[k] = v.eval_p[(size_t)g * G::AP + a];
+            pa[k] = (double)p32[k] * (double)(ok[k] ? 1 : 0);
+        }
         if (a < G::AP) s_pa[grp][a] = pa[k];
     }
+    const float vleaf = live ? v.eval_v[g] : 0.0f;
     __syncthreads();
     double s = 0.0;
     if constexpr (R == 1) {
@@ -377,75 +255,417 @@ __device__ __forceinline__ void expand_body(const View &v, double (*s_pa)[G::AP]
         s = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
         for (int i = NB; i < A; ++i) s = s + s_pa[grp][i];
     }
-    const int node = v.leaf_node[g];
-    const int e = v.n_blk[g];                       // read by all lanes before lane 0 bumps it
-    const int fc = 1 + e * A;
-    const int L = v.path_len[g];
+    if (!live) return;
+    const int node = st.leaf_node;
+    const int e = st.n_blk;
+    const int L = st.path_len;
+    const bool root_exp = L == (R == 1 ? 1 : 0);           // the leaf is the tree's root
+    const bool noisy = root_exp && v.root_noise != nullptr;
+    // the new block: one 16-byte store per child (Node.expand :80-90) + the header
+    int4 *blk = reinterpret_cast<int4 *>(block_ptr(v, g, e));
+#pragma unroll
+    for (int k = 0; k < APL; ++k) {
+        const int a = lane + k * LPG;
+        if (a < A) {
+            // the float32 numerator of the prior: p32 * mask (a masked-out NaN / inf stays what the reference's product gives)
+            const float pm = R != 1 ? (ok[k] ? p32[k] : p32[k] * 0.0f) : (ok[k] ? p32[k] : -1.0f);
+            blk[a] = make_int4(0, __float_as_int(0.0f), 0, __float_as_int(pm));
+            if constexpr (R != 0) v.wsum_d[(size_t)g * v.C + 1 + e * A + a] = 0.0;
+            if (noisy) {
+                // optional root exploration noise (off by default; not in the reference's search, listed in its
+                // src/deepmind_alphazero_pseudocode.py:285-290): prior*(1-eps) + noise*eps on the existing root children
+                const double pr = R != 1 ? pa[k] / s : (ok[k] ? pa[k] : -1.0);
+                v.root_prior[(size_t)g * A + a] = child_exists<R>(pr) ? pr * v.noise_keep + v.root_noise[(size_t)g * A + a] * v.noise_eps : pr;
+            }
+        } else if (a == A) {
+            const double ps = s;
+            blk[A] = make_int4(__double2loint(ps), __double2hiint(ps), noisy ? 1 : 0, node);
+        }
+    }
+    // the value is the evaluator's float32 for the side to move at the leaf (rule set 1: value[state.player],
+    // a float32 widened by .tolist(), search.py:91); signs alternate upwards in both rule sets
+    const WT val = (WT)vleaf;
+#pragma unroll
+    for (int k = 0; k < T::CPL; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                   // backpropagate :214-223 / search.py:48-58
+            int i;
+            if (!path_entry_here<G>(lane, k, j, i) || i >= L) continue;
+            const int nd = comp4(st.sc[k], j);
+            const int dist = L - 1 - i;
+            const WT dv = (dist & 1) ? -val : val;
+            if constexpr (R != 0) { double *w = v.wsum_d + (size_t)g * v.C + nd; *w = *w + dv; }
+            if (nd != 0) {                              // (node 0, a fresh root, keeps its statistics in the slot record: below)
+                NodeChunk *c = node_chunk<G>(v, g, nd);
+                if constexpr (R == 0) {
+                    int2 nw = *reinterpret_cast<int2 *>(c);
+                    nw.x += 1;
+                    nw.y = __float_as_int(__int_as_float(nw.y) + (float)dv);
+                    *reinterpret_cast<int2 *>(c) = nw;
+                } else {
+                    c->n = c->n + 1;
+                }
+            }
+        }
+    if (L > 0 && st.root == 0) {                    // the path starts at the root: node 0 can only be entry 0, distance L - 1
+        st.root_n += 1;
+        if constexpr (R == 0) st.root_w = st.root_w + (float)(((L - 1) & 1) ? -val : val);
+    }
+    if (node == 0) st.root_kid = e + 1;
+    else if (lane == 0) node_chunk<G>(v, g, node)->kid = e + 1;
+    st.n_blk = e + 1;
+    st.pending = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// selection: PUCT descent to the first unexpanded node, leaf step, terminal test
+// ------------------------------------------------------------------------------------------------
+// APPEND: the non-terminal leaves are appended to the group's leaf list here (one atomic per wavefront; the order of
+// the list does not matter to the device evaluators, whose outputs do not depend on a position's place in the batch)
+// instead of by the stable k_compact pass that the host-callback evaluator needs.
+template <class G, int R, bool APPEND>
+__device__ __forceinline__ void select_game(const View &v, int g, int lane, int grp, bool live, SlotRegs<G> &st, int *s_path,
+                                            const Tabs &tb) {
+    using WT = typename std::conditional<R == 0, float, double>::type;
+    using T = TreeGeo<G>;
+    constexpr int A = G::A, LPG = G::LPG, APL = G::APL;
+    constexpr int HL = A % LPG, HK = A / LPG;          // lane and load slot that fetch a block's header chunk
+    int *my_path = s_path + grp * T::D;
+
+    // One dependent round trip per tree level: the lanes fetch the whole record of the node's children with one 16-byte
+    // load each; the chosen child's block index then comes from a shuffle, and below the root N_parent is not loaded
+    // but rebuilt from the children (an expanded node is visited once at expansion and afterwards only on the way to
+    // one of its children: N = 1 + sum N_child).  The position is replayed move by move from the slot's current one.
+    const int root = live ? st.root : 0;
+    int node = root, depth = 0, action = 0;
+    int kid = 0, n_root = 0;                           // 1 + block of the node's children (0 = unexpanded)
+    typename G::B bm = board_zero<G::W>(), bt = board_zero<G::W>();
     if (live) {
+        bm = board_load<G::W>(v.cur_mine, g);
+        bt = board_load<G::W>(v.cur_theirs, g);
+        if (root == 0) { kid = st.root_kid; n_root = st.root_n; }
+        else { const NodeChunk c = *node_chunk<G>(v, g, root); kid = c.kid; n_root = c.n; }
+    }
+    bool walking = live;
+    while (true) {
+        walking = walking && kid != 0;              // Node.expanded() :35-36
+        if (!__any(walking)) break;
+        const int e = kid - 1;
+        const int4 *blk = reinterpret_cast<const int4 *>(block_ptr(v, g, walking ? e : 0));
+        int4 ch[APL];
+#pragma unroll
+        for (int k = 0; k < APL; ++k) {
+            const int c = lane + k * LPG;
+            ch[k] = (walking && c <= A) ? blk[c] : make_int4(0, 0, 0, 0);
+        }
+        WT w[APL];
 #pragma unroll
         for (int k = 0; k < APL; ++k) {
             const int a = lane + k * LPG;
-            if (a >= A) continue;
-            const double pr = R != 1 ? pa[k] / s : (ok[k] ? pa[k] : -1.0);
-            double prior = pr;
-            // optional root exploration noise (off by default; not in the reference's search, listed in its
-            // src/deepmind_alphazero_pseudocode.py:285-290): prior*(1-eps) + noise*eps on the existing root children
-            if (L == (R == 1 ? 1 : 0) && v.root_noise != nullptr && child_exists<R>(pr))      // a root expansion
-                prior = pr * v.noise_keep + v.root_noise[(size_t)g * A + a] * v.noise_eps;
-            v.cnt[base + fc + a] = 0;                   // Node.expand :80-90
-            wsum[base + fc + a] = (WT)0;
-            v.prior[base + fc + a] = prior;
-            v.kids[base + fc + a] = 0;
+            if constexpr (R == 0) w[k] = __int_as_float(ch[k].y);
+            else w[k] = (walking && a < A) ? v.wsum_d[(size_t)g * v.C + 1 + e * A + a] : 0.0;
         }
-        // the value is the evaluator's float32 for the side to move at the leaf (rule set 1: value[state.player],
-        // a float32 widened by .tolist(), search.py:91); signs alternate upwards in both rule sets
-        const WT val = (WT)v.eval_v[j];
-        for (int k = lane; k < L; k += LPG) {           // backpropagate :214-223 / search.py:48-58
-            const int nd = v.path[(size_t)g * v.D + (L - 1 - k)];
-            const WT dv = (k & 1) ? -val : val;
-            wsum[base + nd] = wsum[base + nd] + dv;
-            v.cnt[base + nd] = v.cnt[base + nd] + 1;
+        const double psum = make_double(__shfl(ch[HK].x, HL, LPG), __shfl(ch[HK].y, HL, LPG));
+        const int flags = __shfl(ch[HK].z, HL, LPG);
+        double p[APL];
+        int n[APL];
+        int nsum = 0;
+#pragma unroll
+        for (int k = 0; k < APL; ++k) {
+            const int a = lane + k * LPG;
+            const bool in = walking && a < A;
+            n[k] = in ? ch[k].x : 0;
+            const float pf = __int_as_float(ch[k].w);
+            if (!in) p[k] = R != 1 ? 0.0 : -1.0;                           // lanes without an action: no child
+            else if (flags & 1) p[k] = v.root_prior[(size_t)g * A + a];     // root priors with noise mixed in
+            else if constexpr (R == 1) p[k] = (double)pf;
+            else p[k] = (double)pf / psum;                                 // f64(p32 * mask) / np.sum, :119-121
+            nsum += n[k];
+        }
+        const int nkids = red_add<LPG>(nsum);
+        const int np_ = node == root ? n_root : nkids + 1;
+        double score = -INFINITY;
+        int best = lane;
+#pragma unroll
+        for (int k = 0; k < APL; ++k) {
+            if (child_exists<R>(p[k])) {
+                double q = 0.0, u;
+                if constexpr (R == 0) {
+                    // ucb_score :11-22.  (prior * sqrt(N_parent)) / (n + 1) in float64 [expl_tab = c * sqrt, c = 1
+                    // in the reference]; -(W / n) in float32 (numpy 2.x), promoted for the sum.
+                    u = (p[k] * tab_at(tb.expl, v.expl_tab, v.tab_lds, np_)) / (double)(n[k] + 1);
+                    if (n[k] > 0) {
+                        const float qf = w[k] / (float)n[k];
+                        q = (double)(-qf);
+                    }
+                } else if constexpr (R == 2) {
+                    // the same expression as numpy 1.x evaluates it: W is float64 there (legacy scalar promotion
+                    // of `0.0 + np.float32`), so -(W / n) is a float64 division
+                    u = (p[k] * tab_at(tb.expl, v.expl_tab, v.tab_lds, np_)) / (double)(n[k] + 1);
+                    if (n[k] > 0) q = -(w[k] / (double)n[k]);
+                } else {
+                    // search.py:33-40: child.value + c * prior * sqrt(N) / (1 + n), left to right, all float64
+                    u = ((tab_at(tb.c, v.c_tab, v.tab_lds, np_) * p[k]) * tab_at(tb.sqrt_, v.sqrt_tab, v.tab_lds, np_)) / (double)(1 + n[k]);
+                    if (n[k] > 0) q = w[k] / (double)n[k];
+                }
+                double sc = q + u;
+                if (!(sc == sc)) sc = -INFINITY;    // NaN is never '>' the running best
+                if (sc > score) { score = sc; best = lane + k * LPG; }   // ascending actions within the lane
+            }
+        }
+        // argmax, strict '>' in ascending action order == maximum score, lowest action on ties
+#pragma unroll
+        for (int m = 1; m < LPG; m <<= 1) {
+            const double so = __shfl_xor(score, m, LPG);
+            const int bo = __shfl_xor(best, m, LPG);
+            if (so > score || (so == score && bo < best)) { score = so; best = bo; }
+        }
+        int kc_sel = ch[0].z;
+#pragma unroll
+        for (int k = 1; k < APL; ++k) if (best / LPG == k) kc_sel = ch[k].z;
+        const int next_kid = __shfl(kc_sel, best & (LPG - 1), LPG);
+        if (walking) {
+            if (lane == 0) my_path[depth] = node;
+            // the position below: parent's position + action, seen by the opponent (:135-145)
+            typename G::B nm, nt;
+            G::play(bm, bt, best, nm, nt);
+            bm = nm;
+            bt = nt;
+            action = best;
+            node = 1 + e * A + best;
+            kid = next_kid;
+            ++depth;
         }
     }
-    __syncthreads();                                // all lanes have read n_blk
-    if (live && lane == 0) {
-        v.kids[base + node] = fc;
-        v.blk_parent[(size_t)g * v.E + e] = node;
-        board_store<G::W>(v.st_mine, (size_t)g * v.E + e, mine);
-        board_store<G::W>(v.st_theirs, (size_t)g * v.E + e, theirs);
-        v.n_blk[g] = e + 1;
-        v.pending[g] = 0;
+    (void)action;
+    if (live && lane == 0) my_path[depth] = node;
+    const int L = depth + 1;                        // nodes on the path, root .. leaf
+    __syncthreads();                                // one wave per block: orders the LDS path writes
+
+    // leaf step: the replayed position IS get_next_state + get_canonical_board of the parent's; terminal test :145
+    int term = TERM_NONE;
+    if (live) term = depth > 0 ? G::terminal(bm, bt) : TERM_NONE;      // (depth 0: an unexpanded root, handled by the caller)
+    if (live && term != TERM_NONE) {
+        // terminal leaf: never expanded.  Rule set 0: value in {+1,-1,0} for the side to move at the leaf,
+        // backpropagate :214-223 -- the sign alternates with distance from the leaf (to_play alternates level by
+        // level).  Rule set 1 (search.py:78-80,:48-58): the utility of the player who MOVED into the leaf, added
+        // unchanged to the leaf and to its parent (no flip above a terminal node), alternating from there on.
+        const WT val = R != 1 ? (WT)term : (term == 0 ? (WT)0 : (WT)(-term));
+        for (int k = lane; k < L; k += LPG) {
+            const int nd = my_path[L - 1 - k];
+            const bool neg = R != 1 ? (k & 1) : (k > 0 && ((k - 1) & 1));
+            const WT dv = neg ? -val : val;
+            if constexpr (R != 0) { double *w = v.wsum_d + (size_t)g * v.C + nd; *w = *w + dv; }
+            if (nd != 0) {                              // (a fresh root's statistics: slot record, lane 0 below)
+                NodeChunk *c = node_chunk<G>(v, g, nd);
+                if constexpr (R == 0) {
+                    int2 nw = *reinterpret_cast<int2 *>(c);
+                    nw.x += 1;
+                    nw.y = __float_as_int(__int_as_float(nw.y) + (float)dv);
+                    *reinterpret_cast<int2 *>(c) = nw;
+                } else {
+                    c->n = c->n + 1;
+                }
+            }
+        }
+        if (lane == 0) {
+            SlotHead *h = reinterpret_cast<SlotHead *>(slot_ptr(v, g));
+            h->pending = 0;
+            if (root == 0) {                            // node 0 is path entry 0: distance L - 1 from the leaf
+                const int k0 = L - 1;
+                const bool neg0 = R != 1 ? (k0 & 1) : (k0 > 0 && ((k0 - 1) & 1));
+                h->root_n = st.root_n + 1;
+                if constexpr (R == 0) h->root_w = st.root_w + (float)(neg0 ? -val : val);
+            }
+            atomicAdd(&v.counters[1], 1ull);
+            atomicAdd(&v.counters[2], (unsigned long long)L);
+        }
+    } else if (live) {
+        int32_t *path = reinterpret_cast<int32_t *>(slot_ptr(v, g) + T::PATH_CHUNK * 16);
+        for (int k = lane; k < L; k += LPG) path[k] = my_path[k];
+        if (lane == 0) {
+            SlotHead *h = reinterpret_cast<SlotHead *>(slot_ptr(v, g));
+            h->pending = 1;
+            h->path_len = L;
+            h->leaf_node = node;
+            slot_store_leaf<G>(v, g, bm, bt);
+            atomicAdd(&v.counters[2], (unsigned long long)L);
+        }
     }
+    if constexpr (APPEND) {
+        const bool mine_to_add = live && term == TERM_NONE && lane == 0;
+        const unsigned long long bal = __ballot(mine_to_add);
+        const int cnt = __popcll(bal);
+        int base_j = 0;
+        if (cnt > 0) {
+            const int leader = __ffsll((long long)bal) - 1;
+            if ((int)threadIdx.x == leader) {
+                base_j = atomicAdd(v.nl, cnt);
+                atomicAdd(&v.counters[0], (unsigned long long)cnt);
+            }
+            base_j = __shfl(base_j, leader, 64);
+        }
+        if (mine_to_add) {
+            const int j = v.lo + base_j + __popcll(bal & ((1ull << threadIdx.x) - 1ull));
+            v.leaf_slot[j] = g;
+        }
+    }
+}
+
+// dynamic LDS of the tree kernels: [GPW games][D] path staging, then the exploration table(s)
+template <class G>
+__device__ __forceinline__ double *tab_region(int *s_path) {
+    return reinterpret_cast<double *>(s_path + (((64 / G::LPG) * TreeGeo<G>::D + 1) & ~1));
+}
+template <class G, int R>
+static inline size_t tree_lds_bytes(const View &v) {
+    return (size_t)((((64 / G::LPG) * TreeGeo<G>::D + 1) & ~1)) * sizeof(int) + (size_t)v.tab_lds * (R == 1 ? 2 : 1) * sizeof(double);
+}
+
+template <class G, int R>
+__global__ __launch_bounds__(64) void k_select(View v) {
+    extern __shared__ __attribute__((aligned(16))) int s_path[];                 // [GPW games][D]
+    constexpr int LPG = G::LPG, GPW = 64 / LPG;
+    Tabs tb;
+    stage_tabs<R>(v, tab_region<G>(s_path), tb);
+    const int lane = threadIdx.x & (LPG - 1), grp = threadIdx.x / LPG;
+    const int gl = blockIdx.x * GPW + grp;
+    const bool live = gl < v.n_act;
+    const int g = live ? v.lo + gl : v.lo;
+    SlotRegs<G> st;
+    slot_load<G>(v, g, lane, live, st);
+    __syncthreads();
+    select_game<G, R, false>(v, g, lane, grp, live, st, s_path, tb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stable (slot-order) compaction of the pending leaves; one workgroup
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_compact(View v) {
+    __shared__ int s_sum[1024];
+    const int t = threadIdx.x;
+    const int per = (v.n_act + 1023) / 1024;
+    const int lo = v.lo + t * per, hi = min(lo + per, v.lo + v.n_act);
+    int c = 0;
+    for (int g = lo; g < hi; ++g) c += reinterpret_cast<const SlotHead *>(slot_ptr(v, g))->pending;
+    s_sum[t] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {      // Hillis-Steele inclusive scan
+        int x = (t >= off) ? s_sum[t - off] : 0;
+        __syncthreads();
+        s_sum[t] += x;
+        __syncthreads();
+    }
+    int pos = v.lo + s_sum[t] - c;
+    for (int g = lo; g < hi; ++g)
+        if (reinterpret_cast<const SlotHead *>(slot_ptr(v, g))->pending) v.leaf_slot[pos++] = g;
+    if (t == 1023) {
+        v.nl[0] = s_sum[1023];
+        atomicAdd(&v.counters[0], (unsigned long long)s_sum[1023]);
+    }
+}
+
+template <class G>
+__device__ __forceinline__ void leaf_boards(const View &v, int g, typename G::B &m, typename G::B &t) {
+    const u64 *src = reinterpret_cast<const u64 *>(slot_ptr(v, g) + TreeGeo<G>::LEAF_CHUNK * 16);
+#pragma unroll
+    for (int i = 0; i < G::W; ++i) { m.w[i] = src[i]; t.w[i] = src[G::W + i]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// hash evaluator
+// ------------------------------------------------------------------------------------------------
+template <class G>
+__global__ void k_eval_hash(View v, uint64_t salt) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= v.nl[0]) return;
+    const int g = v.leaf_slot[v.lo + j];
+    typename G::B m, t;
+    leaf_boards<G>(v, g, m, t);
+    float *p = v.eval_p + (size_t)g * G::AP;
+    v.eval_v[g] = hash_eval<G>(m, t, salt, p);
+    for (int a = G::A; a < G::AP; ++a) p[a] = 0.0f;
+}
+
+// host evaluator: results arrive in list order; the tree kernels read them by slot
+template <class G>
+__global__ void k_scatter_eval(View v, const float *p_compact, const float *v_compact) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.nl[0] * G::AP) return;
+    const int j = i / G::AP, a = i % G::AP;
+    const int g = v.leaf_slot[v.lo + j];
+    v.eval_p[(size_t)g * G::AP + a] = p_compact[i];
+    if (a == 0) v.eval_v[g] = v_compact[j];
 }
 
 template <class G, int R>
 __global__ __launch_bounds__(64) void k_expand(View v) {
     __shared__ double s_pa[64 / G::LPG][G::AP];     // staged priors for numpy's pairwise summation
-    expand_body<G, R, false>(v, s_pa);
+    constexpr int LPG = G::LPG, GPW = 64 / LPG;
+    const int lane = threadIdx.x & (LPG - 1), grp = threadIdx.x / LPG;
+    const int gl = blockIdx.x * GPW + grp;
+    const bool in = gl < v.n_act;
+    const int g = in ? v.lo + gl : v.lo;
+    SlotRegs<G> st;
+    slot_load<G>(v, g, lane, in, st);
+    const bool live = in && st.pending != 0;
+    expand_game<G, R>(v, g, lane, grp, live, st, s_pa);
+    if (live && lane == 0) slot_store_head<G>(v, g, st);
 }
 
 // Expansion + backup of the leaves evaluated in round r-1 and the descent of round r in ONE launch: both are per-game
-// work on the same lane mapping, and games do not interact.  The leaves found here are appended to the group's OTHER
+// work on the same lane mapping, and games do not interact.  The game's slot record is loaded once, updated in
+// registers by the expansion and used by the descent.  The leaves found here are appended to the group's OTHER
 // leaf counter (the one this kernel's expand phase read is still in use until the launch ends); the counter for the
 // round after next is zeroed.  Two launches per simulation round (this one + the evaluator) instead of four.
 template <class G, int R>
 __global__ __launch_bounds__(64) void k_expand_select(View v) {
     __shared__ double s_pa[64 / G::LPG][G::AP];
-    extern __shared__ int s_path[];
+    extern __shared__ __attribute__((aligned(16))) int s_path[];
+    constexpr int LPG = G::LPG, GPW = 64 / LPG;
     if (blockIdx.x == 0 && threadIdx.x == 0) v.nl_other[0] = 0;      // the next fused launch appends there
-    expand_body<G, R, true>(v, s_pa);
+    Tabs tb;
+    stage_tabs<R>(v, tab_region<G>(s_path), tb);
+    const int lane = threadIdx.x & (LPG - 1), grp = threadIdx.x / LPG;
+    const int gl = blockIdx.x * GPW + grp;
+    const bool in = gl < v.n_act;
+    const int g = in ? v.lo + gl : v.lo;
+    SlotRegs<G> st;
+    slot_load<G>(v, g, lane, in, st);
+    const bool pend = in && st.pending != 0;
+    expand_game<G, R>(v, g, lane, grp, pend, st, s_pa);
+    if (pend && lane == 0) slot_store_head<G>(v, g, st);
     __syncthreads();
     __threadfence();                                // this game's new children are visible to its own descent
-    select_body<G, R, true>(v, s_path);
+    select_game<G, R, true>(v, g, lane, grp, in, st, s_path, tb);
 }
 
-// compacted leaf positions as int8 cells, for the host evaluator
+// listed leaf positions as int8 cells, for the host evaluator
 template <class G>
 __global__ void k_leaf_cells(View v, int8_t *dst) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= v.nl[0]) return;
     const int g = v.leaf_slot[v.lo + j];
-    board_to_cells<G>(board_load<G::W>(v.leaf_mine, g), board_load<G::W>(v.leaf_theirs, g), dst + (size_t)j * G::CELLS);
+    typename G::B m, t;
+    leaf_boards<G>(v, g, m, t);
+    board_to_cells<G>(m, t, dst + (size_t)j * G::CELLS);
+}
+
+// the block of the root's children: nullptr while the root is unexpanded
+template <class G>
+__device__ __forceinline__ const NodeChunk *root_children(const View &v, int g) {
+    const SlotHead *h = reinterpret_cast<const SlotHead *>(slot_ptr(v, g));
+    const int root = v.reuse ? h->root : 0;
+    const int kid = root == 0 ? h->root_kid : node_chunk<G>(v, g, root)->kid;
+    return kid ? reinterpret_cast<const NodeChunk *>(block_ptr(v, g, kid - 1)) : nullptr;
+}
+// float64 prior of child a of the block `blk` (what Node.prior holds in the reference)
+template <class G, int R>
+__device__ __forceinline__ double child_prior(const View &v, int g, const NodeChunk *blk, int a) {
+    const BlockHead *hd = reinterpret_cast<const BlockHead *>(blk + G::A);
+    if (hd->flags & 1) return v.root_prior[(size_t)g * G::A + a];
+    if constexpr (R == 1) return (double)blk[a].p;
+    return (double)blk[a].p / hd->psum;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -461,18 +681,17 @@ __global__ __launch_bounds__(64) void k_finish(View v, const double *uniforms) {
     const int gl = blockIdx.x * GPW + grp;
     const bool live = gl < v.n_act;
     const int g = live ? gl : 0;
-    const size_t base = (size_t)g * v.C;
     const int len = v.cur_len[g];
     const size_t h = (size_t)g * v.max_plies + len;
-    const int rfc = live ? v.kids[base + (v.reuse ? v.root[g] : 0)] : 1;     // the root's children
+    const NodeChunk *rblk = live ? root_children<G>(v, g) : nullptr;         // the root's children
 #pragma unroll
     for (int k = 0; k < APL; ++k) {
         const int a = lane + k * LPG;
         if (a >= G::AP) continue;
         int c = 0, ex = 0;
-        if (live && a < A) {
-            ex = child_exists<R>(v.prior[base + rfc + a]);      // root.children keys
-            c = ex ? v.cnt[base + rfc + a] : 0;
+        if (rblk != nullptr && a < A) {
+            ex = child_exists<R>(child_prior<G, R>(v, g, rblk, a));      // root.children keys
+            c = ex ? rblk[a].n : 0;
         }
         s_cnt[grp][a] = c;
         s_ex[grp][a] = (unsigned char)ex;
@@ -517,7 +736,10 @@ __global__ __launch_bounds__(64) void k_finish(View v, const double *uniforms) {
     v.cur_len[g] = len + 1;
     v.chosen[g] = act;
     v.h_action[h] = (uint8_t)act;
-    if (v.reuse) v.next_root[g] = term == TERM_NONE ? rfc + act : -1;
+    if (v.reuse) {                                  // node id of the chosen child: 1 + block * A + action
+        const int rb = (int)((reinterpret_cast<const uint8_t *>(rblk) - block_ptr(v, g, 0)) / v.rec_block);
+        reinterpret_cast<SlotHead *>(slot_ptr(v, g))->next_root = term == TERM_NONE ? 1 + rb * A + act : -1;
+    }
     v.done[g] = term != TERM_NONE;
     v.reward[g] = (int8_t)(term == TERM_NONE ? 0 : term);
 }
@@ -664,8 +886,10 @@ __global__ void k_reset_slots(View v) {
     board_store<G::W>(v.cur_theirs, g, initial_board<G>(v.init_theirs));
     v.cur_len[g] = 0;
     v.done[g] = 0;
-    v.pending[g] = 0;
-    if (v.reuse) { v.next_root[g] = -1; v.root[g] = 0; }
+    SlotHead *h = reinterpret_cast<SlotHead *>(slot_ptr(v, g));
+    h->pending = 0;
+    h->next_root = -1;
+    h->root = 0;
 }
 
 template <class G>
@@ -675,7 +899,7 @@ __global__ void k_set_boards(View v, const u64 *mine, const u64 *theirs, int n) 
     board_store<G::W>(v.cur_mine, g, board_load<G::W>(mine, g));
     board_store<G::W>(v.cur_theirs, g, board_load<G::W>(theirs, g));
     v.cur_len[g] = 0;
-    if (v.reuse) v.next_root[g] = -1;
+    reinterpret_cast<SlotHead *>(slot_ptr(v, g))->next_root = -1;
 }
 
 template <class G, int R>
@@ -684,20 +908,22 @@ __global__ void k_root_stats(View v, int32_t *counts, float *child_w, double *pr
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.n_act * G::A) return;
     const int g = i / G::A, a = i % G::A;
-    const size_t base = (size_t)g * v.C + (v.reuse ? v.root[g] : 0);      // the root node
-    const int rfc = v.kids[base] - (v.reuse ? v.root[g] : 0);             // its children, relative to it
-    const double p = v.prior[base + rfc + a];
-    const bool ex = child_exists<R>(p);
-    const double w = ex ? (R == 0 ? (double)v.wsum[base + rfc + a] : v.wsum_d[base + rfc + a]) : 0.0;
-    if (counts) counts[i] = ex ? v.cnt[base + rfc + a] : 0;
+    const SlotHead *h = reinterpret_cast<const SlotHead *>(slot_ptr(v, g));
+    const int root = v.reuse ? h->root : 0;                             // the root node
+    const NodeChunk *blk = root_children<G>(v, g);                      // its children (always expanded after a search)
+    const int rb = blk ? (int)((reinterpret_cast<const uint8_t *>(blk) - block_ptr(v, g, 0)) / v.rec_block) : 0;
+    const double p = blk ? child_prior<G, R>(v, g, blk, a) : 0.0;
+    const bool ex = blk != nullptr && child_exists<R>(p);
+    const double w = ex ? (R == 0 ? (double)blk[a].w : v.wsum_d[(size_t)g * v.C + 1 + rb * G::A + a]) : 0.0;
+    if (counts) counts[i] = ex ? blk[a].n : 0;
     if (child_w) child_w[i] = (float)w;
     if (child_wd) child_wd[i] = w;
     if (prior) prior[i] = ex ? p : 0.0;
     if (a == 0) {
-        const double rw = R == 0 ? (double)v.wsum[base] : v.wsum_d[base];
+        const double rw = R != 0 ? v.wsum_d[(size_t)g * v.C + root] : (root == 0 ? (double)h->root_w : (double)node_chunk<G>(v, g, root)->w);
         if (root_w) root_w[g] = (float)rw;
         if (root_wd) root_wd[g] = rw;
-        if (root_n) root_n[g] = v.cnt[base];
+        if (root_n) root_n[g] = root == 0 ? h->root_n : node_chunk<G>(v, g, root)->n;
     }
 }
 
@@ -742,12 +968,16 @@ __global__ void k_export_dataset(View v, long long first, long long n, float *pl
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// record sizes of the game's tree layout, for the engine's allocations
+void tree_geometry(int game, int32_t *block_bytes, int32_t *slot_bytes, int32_t *path_cap) {
+    GAME_SWITCH(game, { *block_bytes = TreeGeo<G>::BLOCK_BYTES; *slot_bytes = TreeGeo<G>::SLOT_BYTES; *path_cap = TreeGeo<G>::D; });
+}
 void launch_root_prepare(int game, const View &v, hipStream_t s) {
     RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_root_prepare<G, R>), dim3((v.n_act + 255) / 256), dim3(256), 0, s, v));
 }
 void launch_select(int game, const View &v, hipStream_t s) {
     RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select<G, R>), dim3(games_grid<G>(v.n_act)), dim3(64),
-                                                    (size_t)(64 / G::LPG) * v.D * sizeof(int), s, v));
+                                                    (tree_lds_bytes<G, R>(v)), s, v));
 }
 void launch_compact(const View &v, hipStream_t s) { hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, v); }
 void launch_eval_hash(int game, const View &v, uint64_t salt, hipStream_t s) {
@@ -758,10 +988,13 @@ void launch_expand(int game, const View &v, hipStream_t s) {
 }
 void launch_expand_select(int game, const View &v, hipStream_t s) {
     RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expand_select<G, R>), dim3(games_grid<G>(v.n_act)), dim3(64),
-                                                    (size_t)(64 / G::LPG) * v.D * sizeof(int), s, v));
+                                                    (tree_lds_bytes<G, R>(v)), s, v));
 }
 void launch_leaf_cells(int game, const View &v, int8_t *dst, hipStream_t s) {
     GAME_SWITCH(game, hipLaunchKernelGGL(k_leaf_cells<G>, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v, dst));
+}
+void launch_scatter_eval(int game, const View &v, const float *p_compact, const float *v_compact, hipStream_t s) {
+    GAME_SWITCH(game, hipLaunchKernelGGL(k_scatter_eval<G>, dim3((v.n_act * G::AP + 255) / 256), dim3(256), 0, s, v, p_compact, v_compact));
 }
 void launch_finish(int game, const View &v, const double *uniforms, hipStream_t s) {
     RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_finish<G, R>), dim3(games_grid<G>(v.n_act)), dim3(64), 0, s, v, uniforms));
