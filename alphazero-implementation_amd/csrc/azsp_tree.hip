@@ -623,6 +623,10 @@ __global__ __launch_bounds__(64) void k_expand_select(View v) {
     __shared__ double s_pa[64 / G::LPG][G::AP];
     extern __shared__ __attribute__((aligned(16))) int s_path[];
     constexpr int LPG = G::LPG, GPW = 64 / LPG;
+    // These waves share their SIMDs with waves of other slot groups' inference launches, which keep the matrix pipe
+    // (and with it the vector issue port) busy back to back and, being older, win every arbitration: measured 100 us per
+    // launch under load against 22 us alone.  A game's round is a few thousand vector instructions: let them go first.
+    __builtin_amdgcn_s_setprio(3);
     if (blockIdx.x == 0 && threadIdx.x == 0) v.nl_other[0] = 0;      // the next fused launch appends there
     Tabs tb;
     stage_tabs<R>(v, tab_region<G>(s_path), tb);
@@ -636,7 +640,10 @@ __global__ __launch_bounds__(64) void k_expand_select(View v) {
     expand_game<G, R>(v, g, lane, grp, pend, st, s_pa);
     if (pend && lane == 0) slot_store_head<G>(v, g, st);
     __syncthreads();
-    __threadfence();                                // this game's new children are visible to its own descent
+    // A game is expanded and descended by the same lanes of the same wave and no other workgroup touches its records
+    // inside this launch, so the stores above only have to be ordered before this wave's own loads: a workgroup-scope
+    // fence (s_waitcnt) -- an agent-scope fence would write back and invalidate the XCD's L2 from every wave.
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     select_game<G, R, true>(v, g, lane, grp, in, st, s_path, tb);
 }
 
