@@ -166,106 +166,13 @@ __device__ __forceinline__ void tap_mfma(f32x16 (&acc)[MT][NTW], const float *co
     }
 }
 
-// One tap for a wave that owns MT row tiles and ONE column tile: the weights of four k-steps come in one 16-byte
-// load per lane (layout [s / 4][column tile][lane][4]), i.e. one vector-memory instruction per 4 * MT MFMAs.  A global
-// load in the MFMA stream costs matrix-pipe time that a second resident wave does not win back (measured with
-// tools/probe/mfma_rate.hip: 8 B per k-step -> 88 % of the pipe with two waves per SIMD, 16 B per four k-steps -> 100 %).
-// MASK < 0: `rt` (wave-uniform) says which row tiles take part.
-template <int MT, int S, int NT, int MASK>
-__device__ __forceinline__ void tap_mfma_quad(f32x16 (&acc)[MT][1], const float *const (&arow)[MT], const float *wq, uint32_t rt) {
-    if constexpr (MT == 1) {
-        // One row tile per wave (small batches: a workgroup's serial chain sets the launch time): there are registers
-        // to spare, so ALL weight loads of the tap are issued before its first MFMA -- one L2 round trip per tap instead
-        // of one per load (measured: the compiler's own schedule waits for them one at a time, 590 ns each).
-        float4 t[S / 4];
-#pragma unroll
-        for (int q = 0; q < S / 4; ++q) t[q] = *reinterpret_cast<const float4 *>(wq + (size_t)q * NT * 64 * 4);
-#pragma unroll
-        for (int q = 0; q < S / 4; ++q)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float b = k == 0 ? t[q].x : (k == 1 ? t[q].y : (k == 2 ? t[q].z : t[q].w));
-                if (MASK >= 0 ? (MASK & 1) != 0 : (rt & 1u) != 0)
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[0][koff(4 * q + k)], b, acc[0][0], 0, 0, 0);
-            }
-        return;
-    }
-#pragma unroll
-    for (int s = 0; s < S; s += 4) {
-        const float4 t = *reinterpret_cast<const float4 *>(wq + (size_t)(s / 4) * NT * 64 * 4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float b = k == 0 ? t.x : (k == 1 ? t.y : (k == 2 ? t.z : t.w));
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (MASK >= 0 ? ((MASK >> mt) & 1) != 0 : ((rt >> mt) & 1u) != 0)
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[mt][koff(s + k)], b, acc[mt][0], 0, 0, 0);
-            }
-        }
-    }
-}
-
-// Row tile T of one tap over NQ quads of k-steps whose weights are already in registers (q0 = first quad).
-template <int MT, int NQ, int T>
-__device__ __forceinline__ void tap_block(f32x16 (&acc)[MT][1], const float *arow_t, const float4 (&t)[NQ], int q0) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float b = k == 0 ? t[q].x : (k == 1 ? t[q].y : (k == 2 ? t[q].z : t[q].w));
-            acc[T][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow_t[koff(4 * (q0 + q) + k)], b, acc[T][0], 0, 0, 0);
-        }
-}
-
 // `need[mt]` (wave-uniform): taps for which at least one row of row tile mt has an on-board input.  The other
 // taps multiply an all-zero A tile -- adding exactly 0 -- and are skipped (SK kernels order their rows so that
 // whole row tiles share their off-board taps; everywhere else every tap is needed by some row).
 template <class G, int MT, int NTW, int TAPS, int S, int PF, int WST = NTW, bool SK = false>
 __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *__restrict__ wl, const float *act,
                                           const int (&ridx)[MT], const uint32_t (&vmask)[MT], int stride, int zero_idx,
-                                          int lane, const uint32_t (&need)[MT], const float *__restrict__ wq = nullptr) {
-    if constexpr (PF == 0 && NTW == 1 && TAPS == 9 && WST > 1) {
-      if (wq != nullptr) {
-        // waves that own ONE column tile: wq = this wave's column of the quad-step weights
-#if AZSP_UNROLL_TAPS
-#pragma unroll
-#endif
-        for (int tap = 0; tap < 9; ++tap) {
-            uint32_t rt = 0;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) rt |= ((need[mt] >> tap) & 1u) << mt;
-            if (!rt) continue;
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const float *arow[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                arow[mt] = act + (((vmask[mt] >> tap) & 1u) ? ridx[mt] + (dy * G::COLS + dx) * stride : zero_idx);
-            const float *wt = wq + (size_t)tap * (S / 4) * WST * 64 * 4;
-            if constexpr (MT > 1) {
-                // Eight quads (32 k-steps) of weights at a time in registers, then one straight-line block per row tile
-                // that needs the tap.  (One interleaved body per tile mask was 8-15 % slower: the alternative bodies
-                // meeting in one loop made the compiler keep 40-60 residual registers in scratch and schedule worse.)
-                constexpr int NQ = (S / 4) % 8 == 0 ? 8 : (S / 4);
-#pragma unroll
-                for (int q0 = 0; q0 < S / 4; q0 += NQ) {
-                    float4 t[NQ];
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) t[q] = *reinterpret_cast<const float4 *>(wt + (size_t)(q0 + q) * WST * 64 * 4);
-                    if constexpr (MT > 3) if (rt & 8u) tap_block<MT, NQ, (MT > 3 ? 3 : 0)>(acc, arow[MT > 3 ? 3 : 0], t, q0);
-                    if constexpr (MT > 2) if (rt & 4u) tap_block<MT, NQ, (MT > 2 ? 2 : 0)>(acc, arow[MT > 2 ? 2 : 0], t, q0);
-                    if (rt & 1u) tap_block<MT, NQ, 0>(acc, arow[0], t, q0);
-                    if (rt & 2u) tap_block<MT, NQ, 1>(acc, arow[1], t, q0);
-                }
-                continue;
-            }
-            if (rt == (1u << MT) - 1u) tap_mfma_quad<MT, S, WST, (1 << MT) - 1>(acc, arow, wt, rt);
-            else if (MT == 4 && rt == 0xEu) tap_mfma_quad<MT, S, WST, 0xE>(acc, arow, wt, rt);
-            else if (MT == 4 && rt == 0xDu) tap_mfma_quad<MT, S, WST, 0xD>(acc, arow, wt, rt);
-            else tap_mfma_quad<MT, S, WST, -1>(acc, arow, wt, rt);        // partly filled workgroups
-        }
-        return;
-      }
-    }
+                                          int lane, const uint32_t (&need)[MT]) {
     if constexpr (PF == 0 && SK && MT == 2) {
         for (int tap = 0; tap < TAPS; ++tap) {
             const int t9 = (TAPS == 9) ? tap : 4;
@@ -418,6 +325,61 @@ __device__ __forceinline__ void tower_layer(f32x16 (&acc)[4][1], const float *ac
     tower_step<G, GROUP, QPT, NT, STRIDE, 0>(acc, act, ridx, vmask, zero_idx, wq, wb, xa, rbase);
 }
 
+// ------------------------------------------------------------------------------------------------
+// rolled form of the same pipeline, for every other wave that owns MT row tiles x ONE column tile (no tap skipping)
+// ------------------------------------------------------------------------------------------------
+// A 3x3 convolution is 9 * QPT / QC chunks of QC weight quads; every chunk runs the same static body of MT * QC steps
+// (tile-major), so the loop over chunks stays rolled.  As in tower_step: the 16-byte activation read of step i + 2 is
+// issued before the MFMAs of step i (four rotating buffers; MT * QC is a multiple of 4), also across the loop's back
+// edge, and the chunk's last tile reloads each weight quad for the next chunk as soon as it has used it.
+template <int QPT> struct RolledGeo { static constexpr int QC = QPT % 8 == 0 ? 8 : QPT % 12 == 0 ? 12 : QPT; };
+
+template <class G, int STRIDE>
+__device__ __forceinline__ int tower_aindex(int ridx_t, uint32_t vmask_t, int tap, int zero_idx) {       // float index into act
+    return ((vmask_t >> tap) & 1u) ? ridx_t + ((tap / 3 - 1) * G::COLS + (tap % 3 - 1)) * STRIDE : zero_idx;
+}
+
+template <class G, int MT, int QPT, int NT, int STRIDE>
+__device__ __forceinline__ void conv_rolled(f32x16 (&acc)[MT][1], const float *act, const int (&ridx)[MT], const uint32_t (&vmask)[MT],
+                                            int zero_idx, const float *wq, float4 (&wb)[RolledGeo<QPT>::QC]) {
+    constexpr int QC = RolledGeo<QPT>::QC, CPT = QPT / QC, NCHUNK = 9 * CPT, BODY = MT * QC;
+    static_assert(QPT % QC == 0 && BODY % 4 == 0 && BODY >= 4, "chunking");
+    float4 xa[4];
+    // row bases as float indices into `act` (pointers carried around the loop would lose their LDS address space and
+    // turn the reads into flat loads)
+    int base[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) base[t] = tower_aindex<G, STRIDE>(ridx[t], vmask[t], 0, zero_idx);
+    xa[0] = *reinterpret_cast<const float4 *>(act + base[0]);
+    xa[1] = *reinterpret_cast<const float4 *>(act + base[0] + 8);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int c = 0; c < NCHUNK; ++c) {
+        // the next chunk's first tile: where the last two steps of this chunk prefetch from
+        const int cn = c + 1 < NCHUNK ? c + 1 : c;
+        const int tapn = cn / CPT, q0n = (cn % CPT) * QC;
+        const int nbase0 = tower_aindex<G, STRIDE>(ridx[0], vmask[0], tapn, zero_idx) + 8 * q0n;
+        const int q0 = (c % CPT) * QC;
+        const float *wnext = wq + (size_t)(c * QC + QC) * NT * 64 * 4;          // quad 0 of the next chunk
+#pragma unroll
+        for (int i = 0; i < BODY; ++i) {
+            const int t = i / QC, q = i % QC;
+            const int j = i + 2;                                                  // the step whose activations are requested now
+            if (j < BODY) xa[j % 4] = *reinterpret_cast<const float4 *>(act + base[j / QC] + 8 * (q0 + j % QC));
+            else xa[j % 4] = *reinterpret_cast<const float4 *>(act + nbase0 + 8 * (j - BODY));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(xa[i % 4], k), f4c(wb[q], k), acc[t][0], 0, 0, 0);
+            if (t == MT - 1) wb[q] = *reinterpret_cast<const float4 *>(wnext + (size_t)q * NT * 64 * 4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (cn != c && cn % CPT == 0) {                                           // the next chunk opens a new tap
+#pragma unroll
+            for (int t = 0; t < MT; ++t) base[t] = tower_aindex<G, STRIDE>(ridx[t], vmask[t], tapn, zero_idx);
+        }
+    }
+}
+
 // C/D layout of v_mfma_f32_32x32x2_f32: register v of lane l holds
 //   row = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5),  col = l & 31
 __device__ __forceinline__ int cd_row(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
@@ -439,6 +401,9 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     constexpr bool SK = std::is_same<G, Connect4>::value && PF == 0 && ((MT == 2 && RW == 4) || (MT == 4 && RW == 2 && CW == NT));
     // the statically scheduled tower (tower_layer): 6-board workgroups on the 2 x CW wave grid, 64 or 128 channels
     constexpr bool STATIC_TOWER = SK && MT == 4 && RW == 2 && CW == NT && (NT == 2 || NT == 4);
+    // every other wave grid with one column tile per wave: the rolled form of the same software pipeline (conv_rolled)
+    constexpr bool ROLLED = !STATIC_TOWER && PF == 0 && CW == NT && NT >= 2;
+    constexpr int WBN = ROLLED ? RolledGeo<S / 4>::QC : 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *act = smem;                             // [WG_ROWS + 1][STRIDE], 16-byte aligned rows
     constexpr int AP = G::AP;                      // actions padded to a multiple of 8
@@ -559,11 +524,11 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     if constexpr (TR) { if (tid == 0) P.dbg[(size_t)blockIdx.x * 64 + 56] = __builtin_amdgcn_s_memtime(); }   // core-clock counter
 
     // ---- residual blocks (ResBlock.forward resnet.py:21-27) -----------------------------------------
-    float4 wb[8];                                  // STATIC_TOWER: the current chunk of eight weight quads (see tower_layer)
-    if constexpr (STATIC_TOWER) {
+    float4 wb[WBN];                                // STATIC_TOWER / ROLLED: the current chunk of weight quads (tower_layer, conv_rolled)
+    if constexpr (STATIC_TOWER || ROLLED) {
         const float *wq0 = P.conv_w4 + ((size_t)wc * 64 + lane) * 4;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wb[j] = *reinterpret_cast<const float4 *>(wq0 + (size_t)j * NT * 64 * 4);
+        for (int j = 0; j < WBN; ++j) wb[j] = *reinterpret_cast<const float4 *>(wq0 + (size_t)j * NT * 64 * 4);
     }
     for (int layer = 0; layer < 2 * P.blocks; ++layer) {
         const bool second = layer & 1;
@@ -581,9 +546,11 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
             const float *wq = P.conv_w4 + (size_t)layer * P.conv_w_stride + ((size_t)wc * 64 + lane) * 4;
             if (wave == 0) tower_layer<G, 0, S / 4, NT, STRIDE>(acc, act, ridx, vmask, ZERO_IDX + 4 * half, wq, wb);
             else tower_layer<G, 1, S / 4, NT, STRIDE>(acc, act, ridx, vmask, ZERO_IDX + 4 * half, wq, wb);
+        } else if constexpr (ROLLED) {
+            const float *wq = P.conv_w4 + (size_t)layer * P.conv_w_stride + ((size_t)wc * 64 + lane) * 4;
+            conv_rolled<G, MT, S / 4, NT, STRIDE>(acc, act, ridx, vmask, ZERO_IDX + 4 * half, wq, wb);
         } else {
-            conv_mfma<G, MT, NTW, 9, S, PF, NT, SK>(acc, wl + wc * NTW, act, ridx, vmask, STRIDE, ZERO_IDX + 4 * half, lane, need,
-                                                    (CW == NT && P.conv_w4) ? P.conv_w4 + (size_t)layer * P.conv_w_stride + ((size_t)wc * 64 + lane) * 4 : nullptr);
+            conv_mfma<G, MT, NTW, 9, S, PF, NT, SK>(acc, wl + wc * NTW, act, ridx, vmask, STRIDE, ZERO_IDX + 4 * half, lane, need);
         }
         if (layer < 16) STAMP(3 + 3 * layer);
         __syncthreads();                               // every wave is done reading the layer input

@@ -21,19 +21,25 @@ def main():
     ap.add_argument("--blocks", type=int, default=4)
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--f16", action="store_true")
+    ap.add_argument("--game", choices=["connect4", "gomoku9"], default="connect4")
     a = ap.parse_args()
     import torch
     from azsp.model import ResNet
     torch.manual_seed(0)
-    blob = resnet_blob(ResNet((6, 7), 7, a.blocks, a.channels))[0]
+    shape, n_act = ((6, 7), 7) if a.game == "connect4" else ((9, 9), 81)
+    cells = shape[0] * shape[1]
+    blob = resnet_blob(ResNet(shape, n_act, a.blocks, a.channels))[0]
     rng = np.random.RandomState(0)
     for B in a.boards:
-        boards = np.zeros((B, 6, 7), np.int8)
-        for b in boards:                       # random legal-looking fillings (gravity respected)
-            for c in range(7):
-                h = rng.randint(0, 6)
-                b[6 - h:, c] = rng.choice([-1, 1], size=h)
-        with Engine("connect4", B, 1, res_blocks=a.blocks, channels=a.channels, timing=True, f16_split=a.f16) as e:
+        boards = np.zeros((B,) + shape, np.int8)
+        if a.game == "connect4":
+            for b in boards:                       # random legal-looking fillings (gravity respected)
+                for c in range(7):
+                    h = rng.randint(0, 6)
+                    b[6 - h:, c] = rng.choice([-1, 1], size=h)
+        else:
+            boards[:] = rng.choice([-1, 0, 0, 0, 1], size=boards.shape)
+        with Engine(a.game, B, 1, res_blocks=a.blocks, channels=a.channels, timing=True, f16_split=a.f16) as e:
             e.load_resnet(blob)
             e.predict(boards)
             e.reset_stats()
@@ -41,7 +47,8 @@ def main():
                 e.predict(boards)
             st = e.stats()
         ms = st["infer_ms"] / st["infer_launches"]
-        flops = 25254012.0 if (a.blocks, a.channels) == (4, 64) else None
+        ch = a.channels                        # 2 * MAC over conv + linear layers
+        flops = 2.0 * (cells * (3 * 9 * ch + 2 * a.blocks * ch * ch * 9 + ch * 32 + ch * 9 * 3) + 32 * cells * n_act + 3 * cells)
         line = {"boards": B, "launch_ms": round(ms, 4), "boards_per_s": round(B / ms * 1e3)}
         if flops:
             line["tflops"] = round(B * flops / ms / 1e9, 1)
