@@ -118,4 +118,8 @@ class MCTS:
             roots.append(root)
         return roots
 
-    run_single = run
+    def run_single(self, state: np.ndarray, to_play: int) -> Node:
+        """The reference's unbatched search (monte_carlo_tree_search.py:173-212): one tree, one `predict` call per
+        simulation.  It builds the same tree as `run_batch` on a one-element list (SURVEY.md appendix A.11 checked
+        identical visit counts), so it is the same device search."""
+        return self.run_batch([state], [to_play])[0]

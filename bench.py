@@ -56,26 +56,67 @@ def tree_report(st: dict, wall_s: float, n_actions: int = 7) -> dict:
     depth = st["path_nodes"] / max(sims, 1) - 1.0
     bytes_per_sim = depth * n_actions * 20 + 32 + (n_actions * 20 + 24) + (depth + 1.0) * 24
     k_ms = st["select_ms"] + st["expand_ms"]
+    traffic = pmc_traffic("k_expand_select")                       # bytes per launch = one slot group's round
+    sims_per_launch = sims / st["select_launches"] if st.get("select_launches") else 0.0
     gbs = sims * bytes_per_sim / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     return {"select_ms": st["select_ms"], "expand_ms": st["expand_ms"], "play_ms": st["play_ms"],
             "rounds": int(st["rounds"]), "evals": int(st["evals"]), "terminal_leaves": int(st["terminal_leaves"]),
             "path_nodes": int(st["path_nodes"]), "sims_per_s": sims / wall_s, "evals_per_s": st["evals"] / wall_s,
             "mean_levels_selected": depth,
-            "roofline": {"bound": "hbm", "kernels": "k_expand_select (expansion + backup of round r-1, descent of round r)",
-                         "bytes_per_sim": bytes_per_sim,
-                         "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
-                         "traffic": pmc_traffic("k_expand_select")}}
+            "roofline": dict({"bound": "hbm", "kernels": "k_expand_select (expansion + backup of round r-1, descent of round r)",
+                              "bytes_per_sim": bytes_per_sim,
+                              "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                              "traffic": traffic},
+                             **({"traffic_per_sim": traffic / sims_per_launch, "traffic_over_algorithmic": traffic / sims_per_launch / bytes_per_sim}
+                                if traffic and sims_per_launch else {}))}
+
+
+def kernel_source_sha() -> str:
+    """Fingerprint of the HIP sources: ties the committed PMC summary to the kernels it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "alphazero-implementation_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel: str):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate
-    --pmc passes, FETCH_SIZE doubled per the gfx950 correction); None if no summary is present."""
+    """HBM bytes per launch of the kernel from the committed rocprofv3 PMC summary (separate --pmc passes,
+    FETCH_SIZE doubled per the gfx950 correction; tools/pmc_summary.py).  None if no summary is present OR if it was
+    measured on other kernel sources than the ones in the tree (the summary records their fingerprint)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel, {}).get("bytes_per_launch")
+            d = json.load(f)
     except (OSError, ValueError):
         return None
+    if d.get("_source_sha16") != kernel_source_sha():
+        return None
+    return d.get(kernel, {}).get("bytes_per_launch")
+
+
+def combine_ranks(dist, world: int, coll_dev, dt: float, episodes: int, samples: int, gathered_records: int,
+                  gather_s: float) -> dict:
+    """What the ranks exchange after the timed region (also exercised by the 2-rank gloo test): the step time is the
+    MAX over ranks, counts are summed, every rank's own time and all-gather time travel along so that a scaling run
+    explains itself, and the all-gather must have delivered every rank's samples to everyone."""
+    if dist is None:
+        return {"dt": dt, "episodes": episodes, "samples": samples, "per_rank_s": [dt], "allgather_s": [gather_s]}
+    mine = torch.tensor([dt, gather_s], device=coll_dev, dtype=torch.float64)
+    flat = torch.zeros(world * 2, device=coll_dev, dtype=torch.float64)     # (gloo wants the concatenated, flat form)
+    dist.all_gather_into_tensor(flat, mine)
+    allt = flat.view(world, 2)
+    tot = torch.tensor([episodes, samples], device=coll_dev, dtype=torch.int64)
+    dist.all_reduce(tot)
+    episodes, samples = int(tot[0]), int(tot[1])
+    if gathered_records != samples:
+        raise SystemExit(f"rank {dist.get_rank()}: all-gather delivered {gathered_records} records, expected {samples}")
+    allt = allt.cpu()
+    return {"dt": float(allt[:, 0].max()), "episodes": episodes, "samples": samples,
+            "per_rank_s": [float(x) for x in allt[:, 0]], "allgather_s": [float(x) for x in allt[:, 1]]}
 
 
 def cpu_baseline(sims: int, slots: int, state_dict) -> dict:
@@ -138,7 +179,11 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X: the self-play engine has no CPU path")
     # one process per GPU; AZSP_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks
     backend = os.environ.get("AZSP_BENCH_BACKEND", "nccl")
-    local_rank %= torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"bench.py: {world} ranks but only {n_dev} GPU(s) visible: one process per GPU over RCCL needs one device "
+                         f"per rank (AZSP_BENCH_BACKEND=gloo rehearses the collectives with several ranks on fewer GPUs)")
+    local_rank %= n_dev                        # (only the gloo rehearsal mode can have more ranks than devices)
     torch.cuda.set_device(local_rank)
     coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     dist = None
@@ -174,8 +219,11 @@ def main() -> None:
         def step(seed: int):
             np.random.seed(seed)               # independent replica per rank (SURVEY 8e mode B)
             eps = list(gen.generate_episodes(net))
+            tg = time.perf_counter()
             gathered = all_gather_records(gen, dist, world, coll_dev) if dist is not None else None
-            return len(eps), sum(len(e) for e in eps), gathered
+            if gathered is not None and coll_dev.type == "cuda":
+                torch.cuda.synchronize()
+            return len(eps), sum(len(e) for e in eps), gathered, time.perf_counter() - tg
 
         for w in range(args.warmup):
             step(1000 * (w + 1) + rank)
@@ -184,24 +232,23 @@ def main() -> None:
         fence()
         t0 = time.perf_counter()
         episodes = samples = gathered_records = 0
+        gather_s = 0.0
+        t_own = 0.0
         for k in range(args.steps):
-            e, s, g = step(10 * k + rank)
+            ts = time.perf_counter()
+            e, s, g, tg = step(10 * k + rank)
+            t_own += time.perf_counter() - ts
             episodes += e
             samples += s
+            gather_s += tg
             if g is not None:
                 gathered_records += sum(int(x.shape[0]) for x in g)
         fence()
         dt = time.perf_counter() - t0
         st = eng.stats()
-        if dist is not None:
-            t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-            tot = torch.tensor([episodes, samples], device=coll_dev, dtype=torch.int64)
-            dist.all_reduce(tot)
-            episodes, samples = int(tot[0]), int(tot[1])
-            if gathered_records != samples:
-                raise SystemExit(f"rank {rank}: all-gather delivered {gathered_records} records, expected {samples}")
+        # gathered_records counts every rank's records as seen here; samples is this rank's own until combined
+        comb = combine_ranks(dist, world, coll_dev, dt, episodes, samples, gathered_records, gather_s)
+        dt, episodes, samples = comb["dt"], comb["episodes"], comb["samples"]
         eng.close()
         launches = max(int(st["infer_launches"]), 1)
         avg_ms = st["infer_ms"] / launches
@@ -214,10 +261,15 @@ def main() -> None:
         return {
             "value": episodes / dt, "unit": "episodes/s", "ms_per_step": 1e3 * dt / max(args.steps, 1), "dtype": DTYPE[precision],
             "episodes": episodes, "samples": samples,
+            "ranks": {"ms_per_step": [1e3 * x / max(args.steps, 1) for x in comb["per_rank_s"]],
+                      "allgather_ms_per_step": [1e3 * x / max(args.steps, 1) for x in comb["allgather_s"]]},
             "roofline": {"bound": "mfma", "kernel": KERNEL[precision], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": pmc_traffic(KERNEL[precision]), "flops_per_board": fpb,
                          "boards_per_launch": st["infer_boards"] / launches, "avg_launch_ms": avg_ms, "launches": launches,
                          "concurrent_launches": overlap, "busy_ms": union_ms,
+                         # the same without the overlap factor: one launch's flops / its own duration (the launches of the
+                         # three slot groups share the machine, so this is a per-launch share, not the machine's rate)
+                         "per_launch_frac": fpb * st["infer_boards"] / launches / (avg_ms * 1e-3) / 1e12 / peak if avg_ms > 0 else None,
                          "infer_share_of_wall": union_ms * 1e-3 / dt if dt > 0 else None,
                          # Connect-4 kernels skip the 3x3 taps that a whole 32-row tile lacks (exact zeros): 3 of 18
                          # tile-taps per residual conv.  `achieved` stays algorithmic; this is the executed share.
@@ -271,6 +323,7 @@ def main() -> None:
                        "slots_per_gpu": args.slots, "sims": args.sims, "parallelism": f"game-sharded x{world}",
                        "episodes": head["episodes"], "samples": head["samples"],
                        "mean_plies_per_episode": head["samples"] / max(head["episodes"], 1)},
+            "ranks": head["ranks"],
             "roofline": head["roofline"], "tree": head["tree"],
         }
         if other is not None:
@@ -278,6 +331,8 @@ def main() -> None:
             out[key] = {k: other[k] for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "tree")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.sims, args.cpu_slots, net.state_dict())
+        if "cpu_baseline" in out:
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -41,6 +41,73 @@ def _worker(rank: int, world: int, port: int, q):
         dist.destroy_process_group()
 
 
+def _bench_worker(rank: int, world: int, port: int, q):
+    """bench.py's own post-step exchange (combine_ranks) on the all-gathered records of two ranks."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cpu = torch.device("cpu")
+        n = [7, 11][rank]
+        local = torch.from_numpy(pack_records(*_records(rank, n)))
+        parts = all_gather_variable(local, dist, world)
+        got = sum(int(p.shape[0]) for p in parts)
+        out = bench.combine_ranks(dist, world, cpu, dt=1.0 + rank, episodes=3 + rank, samples=n, gathered_records=got, gather_s=0.01 * (rank + 1))
+        ok = (out["dt"] == 2.0 and out["episodes"] == 7 and out["samples"] == 18 and out["per_rank_s"] == [1.0, 2.0]
+              and out["allgather_s"] == [0.01, 0.02])
+        try:                                   # a rank that did not receive everyone's records must stop the bench
+            bench.combine_ranks(dist, world, cpu, dt=1.0, episodes=1, samples=n, gathered_records=got - 1, gather_s=0.0)
+            ok = False
+        except SystemExit:
+            pass
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_rank_combination_gloo_world2():
+    """The N > 1 leg of bench.py (max-over-ranks time, summed counts, per-rank times, all-gather completeness check)
+    with two gloo ranks on the CPU; the single-rank form is the identity."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    one = bench.combine_ranks(None, 1, None, 2.5, 4, 40, 0, 0.0)
+    assert one["dt"] == 2.5 and one["episodes"] == 4 and one["samples"] == 40 and one["per_rank_s"] == [2.5]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results == {0: True, 1: True}
+
+
+def test_pmc_traffic_is_reported_only_for_the_measured_sources(tmp_path, monkeypatch):
+    """roofline.traffic comes from the committed PMC summary; it must go null when the kernels changed since."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    sha = bench.kernel_source_sha()
+    assert len(sha) == 16 and sha == bench.kernel_source_sha()
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda: sha)
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps({"_source_sha16": sha, "k": {"bytes_per_launch": 12.5}}))
+    assert bench.pmc_traffic("k") == 12.5 and bench.pmc_traffic("other") is None
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps({"_source_sha16": "0" * 16, "k": {"bytes_per_launch": 12.5}}))
+    assert bench.pmc_traffic("k") is None
+
+
 def test_pack_unpack_roundtrip():
     s, p, v = _records(0, 17)
     rec = pack_records(s, p, v)

@@ -74,6 +74,11 @@ def test_mcts_facade_matches_reference_fixtures(azsp):
         assert root.select_action(0) == max(root.children, key=lambda a: (root.children[a].visit_count, -a))
     one = mcts.run(np.array(run["boards"][0]), 1)
     assert one.visit_count == run["roots"][0]["n"]
+    single = mcts.run_single(np.array(run["boards"][3]), run["to_plays"][3])       # monte_carlo_tree_search.py:173-212
+    g3 = run["roots"][3]
+    assert single.visit_count == g3["n"] and float(single.value_sum) == g3["w"]
+    assert {a: (c.visit_count, float(c.value_sum), float(c.prior)) for a, c in single.children.items()} == \
+        {int(a): (k["n"], k["w"], k["prior"]) for a, k in g3["kids"].items()}
 
 
 # ------------------------------------------------------------------------------------ episodes

@@ -32,9 +32,20 @@ def main():
         out[k] = {"fetch_kib": f, "write_kib": w, "dispatches": max(nf, nw),
                   "bytes_per_launch": (2 * f + w) * 1024}
     path = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json"
+    # fingerprint of the kernel sources the passes ran on: bench.py reports the traffic only while it matches the tree
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from bench import kernel_source_sha
+        out["_source_sha16"] = kernel_source_sha()
+    except Exception as exc:           # noqa: BLE001  (torch missing etc.: the summary is still useful)
+        out["_source_sha16"] = None
+        print("no source fingerprint:", exc)
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
     for k, v in out.items():
+        if not isinstance(v, dict):
+            continue
         print(f"{k:28s} fetch {v['fetch_kib']:10.1f} KiB  write {v['write_kib']:10.1f} KiB  -> {v['bytes_per_launch'] / 1e6:8.2f} MB/launch")
 
 
