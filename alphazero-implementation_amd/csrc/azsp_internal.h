@@ -52,6 +52,7 @@ struct TreeGeo {
     static constexpr int SLOT_CHUNKS = SLOT_BYTES / 16;
     static constexpr int CPL = (SLOT_CHUNKS + LPG - 1) / LPG;              // slot chunks per lane
     static_assert(APL * LPG >= A + 1, "a block (children + header) must be covered by APL 16-byte loads per lane");
+    static_assert(LPG > PATH_CHUNK, "the slot head and the leaf position come with the first 16-byte load of each lane");
 };
 
 // Device-resident state of one engine.

@@ -100,12 +100,16 @@ template <class G>
 __device__ __forceinline__ void slot_load(const View &v, int g, int lane, bool live, SlotRegs<G> &st) {
     using T = TreeGeo<G>;
     const int4 *src = reinterpret_cast<const int4 *>(slot_ptr(v, g));
-#pragma unroll
-    for (int k = 0; k < T::CPL; ++k) {
-        const int c = lane + k * G::LPG;
-        st.sc[k] = (live && c < T::SLOT_CHUNKS) ? src[c] : make_int4(0, 0, 0, 0);
-    }
+    // the first LPG chunks (head, leaf position, first path entries) at once; the rest of the path only for a descent
+    // deeper than they hold (Connect-4: 16 entries in the first 128 bytes, the other 128 bytes are rarely needed)
+    st.sc[0] = (live && lane < T::SLOT_CHUNKS) ? src[lane] : make_int4(0, 0, 0, 0);
     const int4 c0 = slot_chunk_bcast<G>(st, 0), c1 = slot_chunk_bcast<G>(st, 1), c2 = slot_chunk_bcast<G>(st, 2);
+#pragma unroll
+    for (int k = 1; k < T::CPL; ++k) {
+        const int c = lane + k * G::LPG;
+        const bool need = c0.y > 4 * (k * G::LPG - T::PATH_CHUNK);            // path_len reaches into this round of chunks
+        st.sc[k] = (live && need && c < T::SLOT_CHUNKS) ? src[c] : make_int4(0, 0, 0, 0);
+    }
     st.pending = c0.x; st.path_len = c0.y; st.leaf_node = c0.z; st.n_blk = c0.w;
     st.root = c1.x; st.root_kid = c1.y; st.root_n = c1.z; st.root_w = __int_as_float(c1.w);
     st.next_root = c2.x;
