@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <vector>
 
 #include "azsp_internal.h"
@@ -174,6 +175,91 @@ __device__ __forceinline__ void conv16s(f32x16 (&acc)[NTILE], const h8 *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// statically scheduled tower layer for the 2 x CT wave grid (4 row tiles x one column tile per wave)
+// ------------------------------------------------------------------------------------------------
+// The same idea as tower_layer of the fp32 kernel (azsp_resnet_kernel.h): which tile-taps can be skipped is a static
+// property of the row order, so a layer is one straight-line sequence of steps (tile-tap x 16-deep K slab, three MFMAs
+// each) per row group.  Step i first requests the two activation fragments (hi, lo plane) of step i + 2 (three rotating
+// buffer pairs), then issues its MFMAs.  Weights move in chunks of two slabs (half a tap at 64 channels, 16 registers)
+// through THREE rotating buffers: the first tile of chunk c loads chunk c + 2, so a load has at least a whole chunk of
+// MFMAs to land (two full-tap buffers do not fit beside the accumulators and the residual: 254 spills).  A layer is
+// 18 chunks, a multiple of 3, so every layer finds its first two chunks in buffers 0 and 1.  sched_barrier between steps
+// keeps the compiler from moving the reads back to their uses (the compiler-scheduled form spends half its wave cycles
+// in s_waitcnt: profiles/r02_a_mfma_busy.txt).
+struct TStep16 { int chunk, tap, tile, sl, first_tile; };
+__host__ __device__ constexpr bool tile_needs16(int group, int tile, int tap) {       // row order: build_row_order16(WR = 2)
+    if (tile >= 2) return true;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    if (group == 0) return tile == 0 ? dx != -1 : dy != -1;       // left column, top row
+    return tile == 0 ? dx != 1 : dy != 1;                         // right column, bottom row
+}
+template <int GROUP, int SL>
+struct TowerSched16 {
+    static constexpr int NSTEP = 30 * SL, CPT = SL / 2;            // chunks of two slabs per tap
+    TStep16 s[NSTEP + 2];
+    constexpr TowerSched16() : s{} {
+        int n = 0;
+        for (int tap = 0; tap < 9; ++tap)
+            for (int h = 0; h < CPT; ++h) {
+                int first = 1;
+                for (int tile = 3; tile >= 0; --tile) {
+                    if (!tile_needs16(GROUP, tile, tap)) continue;
+                    for (int k = 0; k < 2; ++k) { s[n].chunk = tap * CPT + h; s[n].tap = tap; s[n].tile = tile; s[n].sl = 2 * h + k; s[n].first_tile = first; ++n; }
+                    first = 0;
+                }
+            }
+        s[n] = s[n - 1]; s[n + 1] = s[n - 1];          // the reads past the end repeat the last one
+    }
+};
+template <int GROUP, int SL>
+struct TowerHolder16 { static constexpr TowerSched16<GROUP, SL> SC{}; };
+
+template <class G, int ROW_BYTES>
+__device__ __forceinline__ int abase16(int abyte_t, uint32_t vmask_t, int tap, int zero_byte) {      // byte offset into the hi plane
+    return ((vmask_t >> tap) & 1u) ? abyte_t + ((tap / 3 - 1) * G::COLS + (tap % 3 - 1)) * ROW_BYTES : zero_byte;
+}
+
+template <class G, int GROUP, int SL, int CT, int ROW_BYTES, int PLANE_BYTES, int I>
+__device__ __forceinline__ void tower16_step(f32x16 (&acc)[4], const unsigned char *lds, const int (&abyte)[4], const uint32_t (&vmask)[4],
+                                             int zero_byte, const h8 *w, h8 (&wh)[3][2], h8 (&wl)[3][2], h8 (&xh)[3], h8 (&xl)[3], int &rbase) {
+    constexpr TStep16 st = TowerHolder16<GROUP, SL>::SC.s[I], nx = TowerHolder16<GROUP, SL>::SC.s[I + 2];
+    constexpr int buf = st.chunk % 3;
+    if constexpr ((nx.sl & 1) == 0 && I + 2 < TowerSched16<GROUP, SL>::NSTEP)        // step i + 2 opens a new (chunk, tile) block
+        rbase = abase16<G, ROW_BYTES>(abyte[nx.tile], vmask[nx.tile], nx.tap, zero_byte);
+    xh[(I + 2) % 3] = *reinterpret_cast<const h8 *>(lds + rbase + nx.sl * 32);
+    xl[(I + 2) % 3] = *reinterpret_cast<const h8 *>(lds + rbase + nx.sl * 32 + PLANE_BYTES);
+    if constexpr (st.first_tile != 0) {            // slab of the chunk after next (past the layer's end: the next layer's)
+        const h8 *wp = w + ((size_t)(st.sl + 4) * CT) * 2 * 64 + (size_t)st.tap * SL * CT * 2 * 64;
+        wh[(st.chunk + 2) % 3][st.sl & 1] = wp[0];
+        wl[(st.chunk + 2) % 3][st.sl & 1] = wp[64];
+    }
+    acc[st.tile] = mfma16(xh[I % 3], wh[buf][st.sl & 1], acc[st.tile]);
+    acc[st.tile] = mfma16(xh[I % 3], wl[buf][st.sl & 1], acc[st.tile]);
+    acc[st.tile] = mfma16(xl[I % 3], wh[buf][st.sl & 1], acc[st.tile]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I + 1 < TowerSched16<GROUP, SL>::NSTEP)
+        tower16_step<G, GROUP, SL, CT, ROW_BYTES, PLANE_BYTES, I + 1>(acc, lds, abyte, vmask, zero_byte, w, wh, wl, xh, xl, rbase);
+}
+
+// One 3x3 convolution of the tower.  w: this lane's pointer to (tap 0, slab 0) of the layer for the wave's column tile;
+// buffers 0 and 1 hold the layer's first two chunks on entry and the next layer's on exit.
+template <class G, int GROUP, int SL, int CT, int ROW_BYTES, int PLANE_BYTES>
+__device__ __forceinline__ void tower16_layer(f32x16 (&acc)[4], const unsigned char *lds, const int (&abyte)[4], const uint32_t (&vmask)[4],
+                                              int zero_byte, const h8 *w, h8 (&wh)[3][2], h8 (&wl)[3][2]) {
+    constexpr TStep16 s0 = TowerHolder16<GROUP, SL>::SC.s[0];
+    static_assert((9 * (SL / 2)) % 3 == 0 && SL % 2 == 0, "chunks per layer must be a multiple of the three weight buffers");
+    int rbase = abase16<G, ROW_BYTES>(abyte[s0.tile], vmask[s0.tile], s0.tap, zero_byte);
+    h8 xh[3], xl[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        xh[i] = *reinterpret_cast<const h8 *>(lds + rbase + i * 32);
+        xl[i] = *reinterpret_cast<const h8 *>(lds + rbase + i * 32 + PLANE_BYTES);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tower16_step<G, GROUP, SL, CT, ROW_BYTES, PLANE_BYTES, 0>(acc, lds, abyte, vmask, zero_byte, w, wh, wl, xh, xl, rbase);
+}
+
 template <class G, int CT, int WR, int ABL = 0>
 __global__ __launch_bounds__(64 * WR * CT, 2)
 void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs, int bstride,
@@ -293,6 +379,18 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     STAMP16(2);
 
     // ---- residual blocks ---------------------------------------------------------------------------------
+    // 64 channels on the 2 x 2 wave grid: the statically scheduled tower (nine taps per layer, so the two weight
+    // buffers swap roles from layer to layer: the layer's parity is a template parameter)
+    constexpr bool STATIC16 = (ABL & 7) == 0 && WR == 2 && (CT == 2 || CT == 4);
+    h8 wh[3][2], wl[3][2];
+    if constexpr (STATIC16) {
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {           // the first two chunks of layer 0
+            const h8 *wp = P.conv_w + (size_t)wc * 2 * 64 + lane + ((size_t)sl * CT) * 2 * 64;
+            wh[sl / 2][sl & 1] = wp[0];
+            wl[sl / 2][sl & 1] = wp[64];
+        }
+    }
     for (int layer = 0; layer < 2 * P.blocks; ++layer) {
         const bool second = layer & 1;
         const float bias = P.conv_b[(size_t)layer * P.conv_b_stride + col];
@@ -301,7 +399,12 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[mt][v] = second ? fmaf(xres[mt][v], up, bias) : bias;
-        if constexpr ((ABL & 7) == 0)
+        if constexpr (STATIC16) {
+            const h8 *wq = P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64 + lane;
+            const int zb = ZERO_BYTE + half * 16;
+            if (wr == 0) tower16_layer<G, 0, SL, CT, ROW_BYTES, PLANE_BYTES>(acc, smem16, abyte, vmask, zb, wq, wh, wl);
+            else tower16_layer<G, 1, SL, CT, ROW_BYTES, PLANE_BYTES>(acc, smem16, abyte, vmask, zb, wq, wh, wl);
+        } else if constexpr ((ABL & 7) == 0)
             conv16s<G, MT, 9, SL, CT>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
                                       abyte, vmask, need, ROW_BYTES, ZERO_BYTE + half * 16, lane);
         else
@@ -582,13 +685,15 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, i
     constexpr size_t planes = (size_t)2 * (F16_ROWS + 1) * RS * 2;
     constexpr size_t heads = ((size_t)F16_ROWS * HB_STRIDE + F16_ROWS * 8 + TB * 8) * 4;
     const size_t lds = (planes > heads ? planes : heads) + F16_ROWS * sizeof(int32_t);   // + the row-order table
-    static bool attr_set[64] = {};
+    // the attribute is per device and idempotent: a racing second call sets the same value
+    static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward_f16<G, CT, WR, ABL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[dev] = true;
+        attr_done.fetch_or(bit, std::memory_order_release);
     }
     const int grid = (max_leaves + TB - 1) / TB;
     Net16Params Q = P;
