@@ -190,6 +190,7 @@ def main() -> None:
     if world > 1 or os.environ.get("AZSP_BENCH_FORCE_DIST") == "1":   # the latter: 1-rank rehearsal of the RCCL calls
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")           # (only the single-process rehearsal runs without a launcher)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=coll_dev)
         else:
