@@ -29,7 +29,7 @@ UNITS = {
     "azsp_resnet_k4.hip": [],
     "azsp_resnet_f16.hip": ["-ftemplate-depth=2048"],
 }
-HEADERS = ["azsp_internal.h", "azsp_games.h", "azsp_resnet_host.h", "azsp_resnet_kernel.h",
+HEADERS = ["azsp_internal.h", "azsp_games.h", "azsp_resnet_host.h", "azsp_resnet_kernel.h", "azsp_tree_dev.h",
            os.path.join("..", "..", "include", "azsp.h")]
 
 

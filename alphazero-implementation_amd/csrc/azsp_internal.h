@@ -32,13 +32,13 @@ struct alignas(16) BlockHead { double psum; int32_t flags; int32_t parent; };
 //   chunk 0  pending (leaf awaits evaluation), path_len (0 for a root expansion: no backup), leaf_node, n_blk
 //   chunk 1  root (node id of the current root; 0 unless the tree is being reused), root_kid (fresh root: 1 + block of its
 //            children, 0 = unexpanded), root_n / root_w (N and W of a fresh root)
-//   chunk 2  next_root (tree reuse: child chosen by k_finish, or -1), padding
+//   chunk 2  next_root (tree reuse: child chosen by k_finish, or -1), sims_done (FUSED rounds: simulations of this ply done)
 //   then     leaf position u64 mine[W], theirs[W]; then int32 path[MAX_PLIES + 2] (root .. leaf of the current descent)
 struct alignas(16) SlotHead {
     int32_t pending, path_len, leaf_node, n_blk;
     int32_t root, root_kid, root_n;
     float root_w;
-    int32_t next_root, pad0, pad1, pad2;
+    int32_t next_root, sims_done, pad1, pad2;
 };
 template <class G>
 struct TreeGeo {
