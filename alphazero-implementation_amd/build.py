@@ -27,6 +27,7 @@ UNITS = {
     "azsp_resnet_k2.hip": ["-ftemplate-depth=2048"],     # the statically scheduled towers compile side by side
     "azsp_resnet_k3.hip": [],
     "azsp_resnet_k4.hip": [],
+    "azsp_resnet_k5.hip": ["-ftemplate-depth=2048"],     # the two large-batch kernels with the tree step fused in
     "azsp_resnet_f16.hip": ["-ftemplate-depth=2048"],
 }
 HEADERS = ["azsp_internal.h", "azsp_games.h", "azsp_resnet_host.h", "azsp_resnet_kernel.h", "azsp_tree_dev.h",

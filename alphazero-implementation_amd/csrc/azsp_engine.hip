@@ -108,6 +108,7 @@ struct azsp_engine {
     double *d_noise = nullptr;        // root exploration noise staging
     float *d_stage_p = nullptr, *d_stage_v = nullptr;   // host evaluator: results in list order before the scatter to slots
     size_t leaf_off = 0;              // byte offset of the leaf position inside a slot record
+    bool fused_rounds_allowed = true; // AZSP_FUSED_ROUNDS=0 at engine creation: keep the two-launch rounds (A/B, tests)
     double *d_st_wd = nullptr, *d_st_rwd = nullptr;   // float64 root statistics staging
     double *d_sqrt = nullptr, *d_ctab = nullptr, *d_expl = nullptr;   // [n_sims + 2] exploration tables
     double c_init = 1.0, c_base = 0.0;
@@ -247,7 +248,7 @@ static int search(azsp_engine *e, int n_act) {
     for (int k = 0; k < G; ++k) {
         gv[k] = e->v;
         gv[k].grp = k;
-        gv[k].nl = e->v.n_leaf + 2 * k;
+        gv[k].nl = e->v.n_leaf + 4 * k;
         gv[k].nl_other = gv[k].nl + 1;
         gv[k].lo = (int)((long long)n_act * k / G);
         gv[k].n_act = (int)((long long)n_act * (k + 1) / G) - gv[k].lo;
@@ -256,12 +257,52 @@ static int search(azsp_engine *e, int n_act) {
         HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
         for (int k = 1; k < G; ++k) HIP_TRY(hipStreamWaitEvent(e->gstream[k], e->ev_fork, 0));
     }
+    // FUSED rounds (AZSP_FUSED_ROUNDS=1 at engine creation; exact-fp32 device network, Connect-4, rule set 0, large
+    // groups): ONE launch per round and group -- the inference kernel expands the leaves it evaluated and finds those
+    // games' next leaves itself (a game whose descent ends on a terminal leaf backs it up and descends again in the same
+    // launch), so there is no tree launch, no gap and no evaluator output in HBM.  Round r reads list r & 1 / counter
+    // r % 3, fills list (r + 1) & 1 / counter (r + 1) % 3 and clears counter (r + 2) % 3 (the one the previous launch
+    // read).  Bit-exact (tested), but NOT the default: measured 2101 against 2209 episodes/s at the headline (128
+    // channels: 290 against 294) -- the tree step is a chain of dependent loads during which the workgroup's other three
+    // waves idle while it keeps one of the CU's two workgroup slots, so both residents are outside their towers more
+    // often and the matrix pipe idles more than the removed launches had cost.
+    bool fused_rounds = e->fused_rounds_allowed && e->evaluator == AZSP_EVAL_RESNET && e->net && e->net_loaded &&
+                        e->cfg.search_rules == AZSP_RULES_SIMPLE && !e->v.reuse && e->v.root_noise == nullptr;
+    for (int k = 0; k < G && fused_rounds; ++k) fused_rounds = resnet_has_fused(e->net, game, gv[k].n_act);
     for (int k = 0; k < G; ++k) {
         hipStream_t st = e->gstream[k];
         launch_root_prepare(game, gv[k], st);
         launch_compact(gv[k], st);
+        if (fused_rounds) continue;              // the roots are evaluated by round 0
         int rc = evaluate_leaves(e, gv[k], st);
         if (rc) return rc;
+    }
+    if (fused_rounds) {
+        for (int r = 0; r <= e->cfg.n_sims; ++r)
+            for (int k = 0; k < G; ++k) {
+                hipStream_t st = e->gstream[k];
+                View w = gv[k];
+                int32_t *cnt = e->v.n_leaf + 4 * k;
+                int32_t *cur_list = (r & 1) ? e->v.leaf_slot2 : e->v.leaf_slot, *next_list = (r & 1) ? e->v.leaf_slot : e->v.leaf_slot2;
+                EventPair *p = ev_begin(e, EV_INFER, st);
+                resnet_forward_fused(e->net, game, w, reinterpret_cast<const u64 *>(w.slot + e->leaf_off), w.slot_bytes / 8,
+                                     cur_list + w.lo, cnt + r % 3, next_list, cnt + (r + 1) % 3, cnt + (r + 2) % 3, w.n_act, st);
+                ev_end(p, st);
+                e->stats.infer_launches++;
+            }
+        for (int k = 1; k < G; ++k) {
+            HIP_TRY(hipEventRecord(e->ev_join[k], e->gstream[k]));
+            HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join[k], 0));
+        }
+        e->v.lo = 0;
+        e->v.grp = 0;
+        e->v.n_act = n_act;
+        hipError_t le2 = hipGetLastError();
+        if (le2 != hipSuccess) return fail(AZSP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le2));
+        e->stats.plies++;
+        e->rounds_host += (uint64_t)e->cfg.n_sims + 1;
+        e->searched = true;
+        return 0;
     }
     // rule set 1: the root expansion is simulation 1 (search.py:66-91)
     const int descents = e->cfg.search_rules == AZSP_RULES_GEN1 ? e->cfg.n_sims - 1 : e->cfg.n_sims;
@@ -278,8 +319,8 @@ static int search(azsp_engine *e, int n_act) {
             if (fused) {
                 // round s + 1 fills the group's counter of parity (s + 1) & 1; the root stage used parity 0
                 View w = gv[k];
-                w.nl = e->v.n_leaf + 2 * k + ((s + 1) & 1);
-                w.nl_other = e->v.n_leaf + 2 * k + (s & 1);
+                w.nl = e->v.n_leaf + 4 * k + ((s + 1) & 1);
+                w.nl_other = e->v.n_leaf + 4 * k + (s & 1);
                 EventPair *p = ev_begin(e, EV_SELECT, st);
                 launch_expand_select(game, w, st);
                 ev_end(p, st);
@@ -304,8 +345,8 @@ static int search(azsp_engine *e, int n_act) {
     if (fused)
         for (int k = 0; k < G; ++k) {           // the last round's leaves (or, with no descent at all, the roots)
             View w = gv[k];
-            w.nl = e->v.n_leaf + 2 * k + (descents & 1);
-            w.nl_other = e->v.n_leaf + 2 * k + ((descents + 1) & 1);
+            w.nl = e->v.n_leaf + 4 * k + (descents & 1);
+            w.nl_other = e->v.n_leaf + 4 * k + ((descents + 1) & 1);
             EventPair *p = ev_begin(e, EV_EXPAND, e->gstream[k]);
             launch_expand(game, w, e->gstream[k]);
             ev_end(p, e->gstream[k]);
@@ -422,6 +463,7 @@ static int create_impl(azsp_engine *e) {
     const azsp_config &c = e->cfg;
     const GameInfo &gi = e->gi;
     ON_DEVICE(c.device);
+    { const char *x = getenv("AZSP_FUSED_ROUNDS"); e->fused_rounds_allowed = x && atoi(x) != 0; }     // opt-in: measured slower (below)
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->gstream[0] = e->stream;
     e->n_groups = c.n_groups > 0 ? (c.n_groups > MAX_GROUPS ? MAX_GROUPS : c.n_groups) : (c.n_slots >= 3072 ? 3 : (c.n_slots >= 1024 ? 2 : 1));
@@ -463,11 +505,12 @@ static int create_impl(azsp_engine *e) {
     HIP_TRY(hipMemset(v.rec, 0, (size_t)N * (size_t)v.rec_slot));
     HIP_TRY(hipMemset(v.slot, 0, (size_t)N * v.slot_bytes));
     DEV_ALLOC(v.root_prior, (size_t)N * A);
-    DEV_ALLOC(v.leaf_slot, N); DEV_ALLOC(v.n_leaf, MAX_GROUPS * 2);
+    DEV_ALLOC(v.leaf_slot, N); DEV_ALLOC(v.leaf_slot2, N); DEV_ALLOC(v.n_leaf, MAX_GROUPS * 4);
     v.nl = v.n_leaf;
     v.nl_other = v.n_leaf + 1;
     HIP_TRY(hipMemset(v.leaf_slot, 0, (size_t)N * sizeof(int32_t)));
-    HIP_TRY(hipMemset(v.n_leaf, 0, MAX_GROUPS * 2 * sizeof(int32_t)));
+    HIP_TRY(hipMemset(v.leaf_slot2, 0, (size_t)N * sizeof(int32_t)));
+    HIP_TRY(hipMemset(v.n_leaf, 0, MAX_GROUPS * 4 * sizeof(int32_t)));
     DEV_ALLOC(v.eval_p, (size_t)N * AP); DEV_ALLOC(v.eval_v, N);
     DEV_ALLOC(e->d_stage_p, (size_t)N * AP); DEV_ALLOC(e->d_stage_v, N);
     e->tab_len = v.reuse ? (S + 1) * gi.max_plies + 2 : S + 2;    // largest N_parent + 1 a search can see

@@ -82,7 +82,8 @@ struct View {
     double  *root_prior;    // [n_slots][A] float64 root priors when root noise was mixed in
     // per-round lists
     int32_t *leaf_slot;     // [n_slots] per group, at offset lo: list of the slots whose leaf awaits evaluation
-    int32_t *n_leaf;        // [MAX_GROUPS][2] leaf counters (two per group: the fused tree kernel alternates them)
+    int32_t *n_leaf;        // [MAX_GROUPS][4] leaf counters (the fused tree kernel alternates two per group, FUSED rounds rotate three)
+    int32_t *leaf_slot2;    // [n_slots] second leaf list (FUSED rounds read one list while filling the other)
     int32_t *nl;            // the counter this launch reads / fills: n_leaf + grp * 2 + parity
     int32_t *nl_other;      // the group's other counter (the fused kernel zeroes it for the round after)
     float   *eval_p;        // [n_slots][AP] evaluator output, indexed by SLOT (AP = A padded to 8)
@@ -159,6 +160,12 @@ size_t resnet_blob_floats(int game, int blocks, int channels);
 // the position of slot g: mine = leaf0 + g * board_stride (W words), theirs = the W words after it
 void resnet_forward(ResNetDev *, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot,
                     const int32_t *n_leaf, int max_leaves, float *out_p, float *out_v, hipStream_t s);
+// FUSED rounds (large-batch Connect-4 kernels of the fp32 network): one launch evaluates the listed leaves AND carries
+// those games on to their next leaf (azsp_tree_dev.h advance_game)
+bool resnet_has_fused(const ResNetDev *, int game, int max_leaves);
+void resnet_forward_fused(ResNetDev *, int game, const View &view, const u64 *leaf0, int board_stride, const int32_t *leaf_slot,
+                          const int32_t *n_leaf, int32_t *next_list, int32_t *next_count, int32_t *zero_count, int max_leaves,
+                          hipStream_t s);
 double resnet_flops_per_board(const ResNetDev *);
 // diagnostics: arm the stamped instantiation for this thread's next fp32 launch; read back its clock / span
 void resnet_trace_next();

@@ -324,12 +324,44 @@ int resnet_forced_variant(int game, int nt) {
     return -1;
 }
 
+// FUSED rounds exist for the large-batch Connect-4 kernels of the exact-fp32 network (64 / 128 channels)
+static void (*fused_launcher(const ResNetDev *n, int game, int max_leaves))(const FwdArgs &) {
+    if (n->f16 || game != 0 || n->forced_variant >= 0) return nullptr;
+    const Variant *v = pick_variant(n, game, max_leaves);
+    if (v && v->launch == fwd_c4_64_big) return fwd_c4_64_big_fused;
+    if (v && v->launch == fwd_c4_128_big) return fwd_c4_128_big_fused;
+    return nullptr;
+}
+bool resnet_has_fused(const ResNetDev *n, int game, int max_leaves) { return n && fused_launcher(n, game, max_leaves) != nullptr; }
+
+static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
+                         int max_leaves, float *out_p, float *out_v, hipStream_t s, const FusedArgs *fused);
+
 void resnet_forward(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
                     int max_leaves, float *out_p, float *out_v, hipStream_t s) {
+    forward_impl(n, game, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s, nullptr);
+}
+
+// One FUSED round of a slot group: evaluates the leaves listed in leaf_slot[0 .. *n_leaf) and carries those games on
+// (expansion, backup, next descent); their next leaves land in next_list / next_count, zero_count is cleared.
+void resnet_forward_fused(ResNetDev *n, int game, const View &view, const u64 *leaf0, int board_stride, const int32_t *leaf_slot,
+                          const int32_t *n_leaf, int32_t *next_list, int32_t *next_count, int32_t *zero_count, int max_leaves,
+                          hipStream_t s) {
+    FusedArgs f;
+    f.v = view;
+    f.next_list = next_list;
+    f.next_count = next_count;
+    f.zero_count = zero_count;
+    forward_impl(n, game, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, nullptr, nullptr, s, &f);
+}
+
+static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
+                         int max_leaves, float *out_p, float *out_v, hipStream_t s, const FusedArgs *fused) {
     if (n->f16) { resnet16_forward(n->f16, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }
     const Variant *v = pick_variant(n, game, max_leaves);
     if (!v) return;                        // resnet_create refused every geometry without a variant
     FwdArgs a;
+    a.fused = fused;
     NetParams &P = a.P;
     const float *d = n->d_blob;
     P.stem_w = d + n->o_stem_w; P.stem_b = d + n->o_stem_b;
@@ -346,7 +378,8 @@ void resnet_forward(ResNetDev *n, int game, const u64 *leaf0, int board_stride, 
     P.conv_w4 = n->has_w4 ? d + n->o_conv_w4 : nullptr;
     a.mine = leaf0; a.theirs = leaf0 + n->g_words; a.bstride = board_stride; a.leaf_slot = leaf_slot; a.n_leaf = n_leaf; a.max_leaves = max_leaves;
     a.out_p = out_p; a.out_v = out_v; a.s = s;
-    v->launch(a);
+    if (fused) fused_launcher(n, game, max_leaves)(a);
+    else v->launch(a);
 }
 
 }  // namespace azsp

@@ -38,6 +38,7 @@
 
 #include "azsp_internal.h"
 #include "azsp_resnet_host.h"
+#include "azsp_tree_dev.h"
 
 namespace azsp {
 
@@ -66,6 +67,14 @@ struct ResNetDev {
     bool has_w4 = false;
     int g_words = 1;              // 64-bit words per side of a position (game trait W)
     int forced_variant = -1;      // index into the variant table if AZSP_RESNET_VARIANT named one at creation, else -1
+};
+
+// FUSED rounds: what the inference kernel needs to carry its games on after evaluating them (advance_game)
+struct FusedArgs {
+    View v;                      // lo / n_act of the slot group, counters, tables
+    int32_t *next_list;          // the leaf list the NEXT launch evaluates (indexed from the group's first slot)
+    int32_t *next_count;         // its length counter (zero on entry)
+    int32_t *zero_count;         // the counter of the launch after next: zeroed here
 };
 
 struct NetParams {
@@ -384,10 +393,11 @@ __device__ __forceinline__ void conv_rolled(f32x16 (&acc)[MT][1], const float *a
 //   row = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5),  col = l & 31
 __device__ __forceinline__ int cd_row(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
 
-template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4, bool TR = false>
+template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4, bool TR = false, bool FUSED = false>
 __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 && NT <= 2 ? 3 : (RW * CW == 16 ? 1 : (RW * CW > 8 ? RW * CW / 4 : (RW * CW == 8 && RW * MT == 8 ? 1 : 2))))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs, int bstride,
                                                          const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
-                                                         float *__restrict__ out_p, float *__restrict__ out_v) {
+                                                         float *__restrict__ out_p, float *__restrict__ out_v,
+                                                         typename std::conditional<FUSED, FusedArgs, int>::type F) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
     constexpr int WG_ROWS = RW * 32 * MT;          // RW row groups x MT row tiles of 32 (x CW column groups of waves)
     constexpr int WROWS = 32 * MT;                 // rows per wave
@@ -416,6 +426,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     float *part = L::PART_ALIAS ? act + 32 : smem + L::PART;
     constexpr int PSTR = L::PART_ALIAS ? STRIDE : 8;
 
+    if constexpr (FUSED) { if (blockIdx.x == 0 && threadIdx.x == 0) F.zero_count[0] = 0; }
     const int n_leaf = *n_leaf_p;
     const int board0 = blockIdx.x * TB;
     if (board0 >= n_leaf) return;
@@ -789,12 +800,47 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
         float den = 0.0f;
 #pragma unroll 1
         for (int a = 0; a < A; ++a) den += G::legal(bmine, btheirs, a) ? expf(lg[a] - mx) : 0.0f;
+        const float val = tanhf(vlogit ? vlogit[tid] : lg[7]);
+        if constexpr (FUSED) {
+            // the results stay in LDS (probabilities over the logits, value in vl): this workgroup expands the leaves itself
 #pragma unroll 1
-        for (int a = 0; a < AP; ++a)
-            out_p[(size_t)slot * AP + a] = (a < A && G::legal(bmine, btheirs, a)) ? expf(lg[a] - mx) / den : 0.0f;     // results by slot
-        out_v[slot] = tanhf(vlogit ? vlogit[tid] : lg[7]);
+            for (int a = 0; a < AP; ++a)
+                logits[tid * AP + a] = (a < A && G::legal(bmine, btheirs, a)) ? expf(lg[a] - mx) / den : 0.0f;
+            vl[tid] = val;
+        } else {
+#pragma unroll 1
+            for (int a = 0; a < AP; ++a)
+                out_p[(size_t)slot * AP + a] = (a < A && G::legal(bmine, btheirs, a)) ? expf(lg[a] - mx) / den : 0.0f;     // results by slot
+            out_v[slot] = val;
+        }
     }
     STAMP(55);
+    if constexpr (FUSED) {
+        // ---- the games go on: expansion + backup, then descents until the next leaf that needs the network ----------
+        // (advance_game, azsp_tree_dev.h; one wave, LPG lanes per game; scratch over the dead activation rows)
+        static_assert(std::is_same<G, Connect4>::value && TB <= 64 / G::LPG, "one wave carries the workgroup's games");
+        double (*s_pa)[G::AP] = reinterpret_cast<double (*)[G::AP]>(act);
+        int *s_path = reinterpret_cast<int *>(act + 2 * (64 / G::LPG) * G::AP);
+        double *s_tab = reinterpret_cast<double *>(s_path + (((64 / G::LPG) * TreeGeo<G>::D + 1) & ~1));
+        const int ntab = F.v.tab_lds;
+        for (int i = tid; i < ntab; i += NTHREADS) s_tab[i] = F.v.expl_tab[i];
+        __syncthreads();
+        if (tid < 64) {
+            Tabs tb;
+            tb.expl = s_tab; tb.sqrt_ = s_tab; tb.c = s_tab;
+            const int ln = tid & (G::LPG - 1), grp = tid / G::LPG;
+            const bool live = grp < TB && board0 + grp < n_leaf;
+            const int g = live ? leaf_slot[board0 + grp] : F.v.lo;
+            float p32[G::APL];
+#pragma unroll
+            for (int k = 0; k < G::APL; ++k) {
+                const int a = ln + k * G::LPG;
+                p32[k] = (live && a < A) ? logits[grp * AP + a] : 0.0f;
+            }
+            const float vleaf = live ? vl[grp] : 0.0f;
+            advance_game<G, 0>(F.v, g, ln, grp, live, p32, vleaf, s_pa, s_path, tb, F.next_list, F.next_count);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -808,6 +854,7 @@ struct FwdArgs {
     int max_leaves;
     float *out_p, *out_v;
     hipStream_t s;
+    const FusedArgs *fused;                 // FUSED variants only, else nullptr
 };
 
 // tracing state lives in azsp_resnet.hip (one copy for all kernel translation units)
@@ -832,7 +879,7 @@ static void trace_forward(const NetParams &P, int grid, Launch launch, hipStream
 }
 
 // TRACEABLE: also instantiate the stamped diagnostic form of this variant (the headline kernel only)
-template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4, bool TRACEABLE = false>
+template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4, bool TRACEABLE = false, bool FUSED = false>
 static void launch_forward(const FwdArgs &a) {
     using L = LdsLayout<G, NT, MT, CW, RW>;
     constexpr int TB = L::TB;
@@ -844,7 +891,7 @@ static void launch_forward(const FwdArgs &a) {
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT, MT, PF, CW, RW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT, MT, PF, CW, RW, false, FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if constexpr (TRACEABLE)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward<G, NT, MT, PF, CW, RW, true>),
@@ -857,17 +904,24 @@ static void launch_forward(const FwdArgs &a) {
         if (resnet_trace_wanted(&print)) {
             trace_forward(a.P, grid, [&](const NetParams &Q) {
                 hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW, true>), dim3(grid), dim3(64 * RW * CW), lds, a.s, Q,
-                                   a.mine, a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v); }, a.s, print);
+                                   a.mine, a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, 0); }, a.s, print);
             return;
         }
     }
-    hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW>), dim3(grid), dim3(64 * RW * CW), lds, a.s, a.P, a.mine, a.theirs,
-                       a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v);
+    if constexpr (FUSED) {
+        hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW, false, true>), dim3(grid), dim3(64 * RW * CW), lds, a.s, a.P, a.mine,
+                           a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, *a.fused);
+    } else {
+        hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW>), dim3(grid), dim3(64 * RW * CW), lds, a.s, a.P, a.mine, a.theirs,
+                           a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, 0);
+    }
 }
 
 // One function per compiled kernel variant (azsp_resnet_k*.hip); the table that picks among them is in azsp_resnet.hip.
 void fwd_c4_64_big(const FwdArgs &);      // Connect-4, 64 ch, 6 boards / workgroup, 2 x 2 waves, static tower (+ traced form)
 void fwd_c4_128_big(const FwdArgs &);     // Connect-4, 128 ch, 6 boards / workgroup, 2 x 4 waves, static tower
+void fwd_c4_64_big_fused(const FwdArgs &);    // the same two with the tree step of the evaluated games fused in (FUSED rounds)
+void fwd_c4_128_big_fused(const FwdArgs &);
 void fwd_c4_32_small(const FwdArgs &);    // Connect-4, 32 ch, 3 boards / workgroup, double-buffered weight stream
 void fwd_c4_32_big(const FwdArgs &);      // Connect-4, 32 ch, 6 boards / workgroup, tap skipping
 void fwd_c4_64_one(const FwdArgs &);      // Connect-4, 64 ch, 1 board / workgroup (latency-bound batches)

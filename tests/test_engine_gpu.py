@@ -564,6 +564,46 @@ def test_device_dataset_and_json_writer_match_reference_output(azsp, tmp_path):
     assert load_episodes(os.path.join(GOLDEN, "episodes_wire.json")) == eps
 
 
+def test_fused_rounds_bit_exact_vs_oracle_and_vs_two_launch_rounds(azsp, monkeypatch):
+    """Large slot groups of the exact-fp32 Connect-4 network can run FUSED rounds (opt-in, AZSP_FUSED_ROUNDS=1; measured
+    slower than the default two launches per round, kept as a tested alternative): the inference kernel expands the leaves it
+    evaluated and finds those games' next leaves itself, a game that hits terminal leaves doing several simulations in
+    one launch.  No result may change: 1024 games (one group) against the C oracle fed by the device network, and a
+    3-group run against the same engine with the two-launch rounds (AZSP_FUSED_ROUNDS=0), bit for bit, including the
+    evaluation accounting."""
+    import torch
+    from azsp.weights import resnet_blob
+    monkeypatch.setenv("AZSP_FUSED_ROUNDS", "1")            # opt-in (read when an engine is created)
+    torch.manual_seed(11)
+    net = azsp.ResNet((6, 7), 7, 2, 64).eval()
+    blob, blocks, ch = resnet_blob(net)
+    n, sims, seed = 1024, 10, 4
+    with _engine(azsp, "connect4", 1024, 1, res_blocks=blocks, channels=ch) as pe:
+        pe.load_resnet(blob)
+        cb = co.make_predict_cb(lambda bs: pe.predict(np.stack(bs)), (6, 7), 7)
+        ref = co.generate("connect4", sims, n, seed=seed, predict_cb=cb, trace=False)
+    np.random.seed(seed)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), n_groups=1)
+    eps = list(gen.generate_episodes(net))
+    assert float(np.random.random_sample()) == ref["next_uniform"]
+    _assert_equals_c_oracle(eps, ref, n)
+    st = gen.last_stats
+    assert st["select_launches"] == 0 and st["infer_launches"] == st["plies"] * (sims + 1)      # one launch per round
+    assert st["evals"] == ref["stats"][0] and st["terminal_leaves"] == ref["stats"][1] and st["path_nodes"] == ref["stats"][3]
+
+    def run(fused):
+        monkeypatch.setenv("AZSP_FUSED_ROUNDS", "1" if fused else "0")
+        np.random.seed(9)
+        g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, 40, 3000, 1, 1))
+        out = list(g.generate_episodes(net))
+        return out, g.last_stats, float(np.random.random_sample())
+    a, sa, ra = run(True)
+    b, sb, rb = run(False)
+    assert sa["select_launches"] == 0 and sb["select_launches"] > 0
+    assert ra == rb and a == b
+    assert (sa["evals"], sa["terminal_leaves"], sa["path_nodes"]) == (sb["evals"], sb["terminal_leaves"], sb["path_nodes"])
+
+
 def test_error_paths(azsp):
     from azsp._lib import AzspError
     with pytest.raises(AzspError):
