@@ -495,24 +495,28 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[mt][nt][v] = bias;
         }
+        // the 27 binary inputs of a row (K index kk = tap * 3 + plane: empty / mine / theirs at the tapped cell), once per tile
+        uint32_t inbits[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            uint32_t ib = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if ((vmask[mt] >> tap) & 1u) {
+                    const int bit = G::bit_of(ry[mt] + tap / 3 - 1, rx[mt] + tap % 3 - 1);
+                    const uint32_t mi = board_bit(bm[mt], bit) ? 1u : 0u, th = board_bit(bt[mt], bit) ? 1u : 0u;
+                    ib |= (((1u - mi) * (1u - th)) | (mi << 1) | (th << 2)) << (3 * tap);
+                }
+            }
+            inbits[mt] = ib;
+        }
         for (int s = 0; s < 14; ++s) {
-            const int kk = 2 * s + half;               // K index = tap*3 + plane, 27 real + 1 zero
-            const int tap = kk / 3, plane = kk % 3;
+            const int kk = 2 * s + half;               // 27 real + 1 zero (bit 27 is never set)
             float w[NTW];
             load_w<NTW>(P.stem_w + ((size_t)s * 64 + lane) * NT + wc * NTW, w);
             float a[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float val = 0.0f;
-                if (kk < 27 && ((vmask[mt] >> tap) & 1u)) {
-                    const int yy = ry[mt] + tap / 3 - 1, xx = rx[mt] + tap % 3 - 1;
-                    const int bit = G::bit_of(yy, xx);
-                    const int mi = board_bit(bm[mt], bit) ? 1 : 0, th = board_bit(bt[mt], bit) ? 1 : 0;
-                    const int on = plane == 0 ? (1 - mi) * (1 - th) : (plane == 1 ? mi : th);
-                    val = (float)on;
-                }
-                a[mt] = val;
-            }
+            for (int mt = 0; mt < MT; ++mt) a[mt] = ((inbits[mt] >> kk) & 1u) ? 1.0f : 0.0f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -789,7 +793,39 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     __syncthreads();
     STAMP(54);
     // ---- masked softmax + tanh (ResNet.predict resnet.py:143-151; legal = the game's valid moves) --------
-    if (tid < TB && board0 + tid < n_leaf) {
+    if constexpr (A <= 7) {
+        // eight lanes per board (one per action, the eighth holds the value logit): every lane exponentiates once, the
+        // denominator is summed in action order exactly like the serial form (0 + e0 + e1 + ...), which the wide-action
+        // form below still is
+        if (tid < TB * 8) {
+            const int b = tid >> 3, a = tid & 7;
+            const bool liveb = board0 + b < n_leaf;
+            const int slot = liveb ? leaf_slot[board0 + b] : 0;
+            const typename G::B bmine = board_load_strided<G::W>(mine, slot, bstride), btheirs = board_load_strided<G::W>(theirs, slot, bstride);
+            const bool leg = liveb && a < A && G::legal(bmine, btheirs, a);
+            const float x = logits[b * AP + a];
+            float mx = leg ? x : -INFINITY;
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 8));
+            const float ex = leg ? expf(x - mx) : 0.0f;
+            float den = 0.0f;
+#pragma unroll
+            for (int k = 0; k < A; ++k) den += __shfl(ex, k, 8);
+            const float pr = leg ? ex / den : 0.0f;
+            const float val = tanhf(x);                          // meaningful in lane 7 (the value logit)
+            if (liveb) {
+                if constexpr (FUSED) {
+                    // the results stay in LDS (probabilities over the logits, value in vl): this workgroup expands the leaves itself
+                    logits[b * AP + a] = pr;
+                    if (a == 7) vl[b] = val;
+                } else {
+                    out_p[(size_t)slot * AP + a] = pr;           // results by slot
+                    if (a == 7) out_v[slot] = val;
+                }
+            }
+        }
+    } else if (tid < TB && board0 + tid < n_leaf) {
+        static_assert(A <= 7 || !FUSED, "FUSED rounds exist for Connect-4");
         const int j = board0 + tid;
         const int slot = leaf_slot[j];
         const typename G::B bmine = board_load_strided<G::W>(mine, slot, bstride), btheirs = board_load_strided<G::W>(theirs, slot, bstride);
@@ -800,19 +836,10 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
         float den = 0.0f;
 #pragma unroll 1
         for (int a = 0; a < A; ++a) den += G::legal(bmine, btheirs, a) ? expf(lg[a] - mx) : 0.0f;
-        const float val = tanhf(vlogit ? vlogit[tid] : lg[7]);
-        if constexpr (FUSED) {
-            // the results stay in LDS (probabilities over the logits, value in vl): this workgroup expands the leaves itself
 #pragma unroll 1
-            for (int a = 0; a < AP; ++a)
-                logits[tid * AP + a] = (a < A && G::legal(bmine, btheirs, a)) ? expf(lg[a] - mx) / den : 0.0f;
-            vl[tid] = val;
-        } else {
-#pragma unroll 1
-            for (int a = 0; a < AP; ++a)
-                out_p[(size_t)slot * AP + a] = (a < A && G::legal(bmine, btheirs, a)) ? expf(lg[a] - mx) / den : 0.0f;     // results by slot
-            out_v[slot] = val;
-        }
+        for (int a = 0; a < AP; ++a)
+            out_p[(size_t)slot * AP + a] = (a < A && G::legal(bmine, btheirs, a)) ? expf(lg[a] - mx) / den : 0.0f;     // results by slot
+        out_v[slot] = tanhf(vlogit ? vlogit[tid] : lg[7]);
     }
     STAMP(55);
     if constexpr (FUSED) {
