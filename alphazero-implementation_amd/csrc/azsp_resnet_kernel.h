@@ -117,6 +117,47 @@ struct LdsLayout {
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
+// Every convolution puts the WEIGHTS on the A side of v_mfma_f32_32x32x2_f32 and the activations on the B side
+// (D = W^T * act^T; both operands have the same lane layout, so nothing else changes): a lane's 16 results of a 32 x 32
+// tile then belong to ONE board cell (GEMM row `lane & 31` of the row tile) and 16 output channels -- channel
+// (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5) of the column tile in register v -- i.e. four runs of four consecutive
+// channels, which an epilogue stores with four 16-byte LDS writes at its own row (no per-value address, no row
+// permutation lookup) where the cell-per-register layout needed sixteen 4-byte ones.
+__device__ __forceinline__ f32x16 conv_mma(float a_act, float w, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(w, a_act, c, 0, 0, 0);
+}
+// The same MFMA as conv_mma with the result in registers of its own, as inline assembly: the statically scheduled tower
+// starts a tile's accumulators from the block input (second convolution of a block) or from the bias (first) at the
+// tile's first MFMA, under a branch on the layer's parity -- written with the builtin on both arms, the optimiser merges
+// the two MFMAs behind a 16-register select, which is the copy this form exists to avoid.
+__device__ __forceinline__ f32x16 conv_mma_from(float a_act, float w, const f32x16 &c) {
+    f32x16 d;
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(w), "v"(a_act), "v"(c));
+    return d;
+}
+// max(x, 0) as ONE instruction (fmaxf compiles to a canonicalising v_max_f32 x, x, x in front of it; the result is the
+// same: a NaN input gives 0 either way)
+__device__ __forceinline__ float relu(float x) {
+    float r;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+// the 16 per-channel constants (bias) of a lane for the column tile whose channel 0 is at b
+__device__ __forceinline__ f32x16 channel_vec(const float *b, int half) {
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 t = *reinterpret_cast<const float4 *>(b + 8 * i + 4 * half);
+        r[4 * i] = t.x; r[4 * i + 1] = t.y; r[4 * i + 2] = t.z; r[4 * i + 3] = t.w;
+    }
+    return r;
+}
+// a lane's 16 results to its row: dst = act + row * STRIDE + 4 * (lane >> 5) + first channel of the column tile
+__device__ __forceinline__ void store_tile(float *dst, const f32x16 &o) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(dst + 8 * i) = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+}
+
 template <int NT>
 __device__ __forceinline__ void load_w(const float *p, float (&w)[NT]) {
     if constexpr (NT == 1) { w[0] = p[0]; }
@@ -151,7 +192,7 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[MT][NTW], const float *
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], w[i][nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = conv_mma(a[mt], w[i][nt], acc[mt][nt]);
     }
 }
 
@@ -170,7 +211,7 @@ __device__ __forceinline__ void tap_mfma(f32x16 (&acc)[MT][NTW], const float *co
             if ((MASK >> mt) & 1) {
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], w[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = conv_mma(a[mt], w[nt], acc[mt][nt]);
             }
     }
 }
@@ -220,7 +261,7 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], w[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = conv_mma(a[mt], w[nt], acc[mt][nt]);
             }
         }
         return;
@@ -267,7 +308,7 @@ __device__ __forceinline__ void conv_mfma(f32x16 (&acc)[MT][NTW], const float *_
 // of its first use, in place, no second buffer.  __builtin_amdgcn_sched_barrier(0) between steps keeps the compiler
 // from re-serialising reads and MFMAs.  Measured (tools/probe/tower_loop.hip, one workgroup per CU): 66.5 cycles per
 // v_mfma_f32_32x32x2_f32 against 71.0 for the compiler-scheduled block form with the same register pressure.
-struct TStep { int tap, tile, q, last_tile; };
+struct TStep { int tap, tile, q, last_tile, first; };      // first: the tile's first step of the layer
 __host__ __device__ constexpr bool tile_needs(int group, int tile, int tap) {
     if (tile >= 2) return true;
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -280,11 +321,16 @@ struct TowerSched {
     TStep s[NSTEP + 2];
     constexpr TowerSched() : s{} {
         int n = 0;
+        bool seen[4] = {false, false, false, false};
         for (int tap = 0; tap < 9; ++tap)
             for (int ch = 0; ch < QPT / 8; ++ch) {
                 for (int tile = 3; tile >= 0; --tile) {
                     if (!tile_needs(GROUP, tile, tap)) continue;
-                    for (int q = 0; q < 8; ++q) { s[n].tap = tap; s[n].tile = tile; s[n].q = ch * 8 + q; s[n].last_tile = 0; ++n; }
+                    for (int q = 0; q < 8; ++q) {
+                        s[n].tap = tap; s[n].tile = tile; s[n].q = ch * 8 + q; s[n].last_tile = 0; s[n].first = seen[tile] ? 0 : 1;
+                        seen[tile] = true;
+                        ++n;
+                    }
                 }
                 for (int q = 0; q < 8; ++q) s[n - 8 + q].last_tile = 1;
             }
@@ -303,26 +349,34 @@ __device__ __forceinline__ const float *tower_abase(const float *act, int ridx_t
 }
 
 template <class G, int GROUP, int QPT, int NT, int STRIDE, int I>
-__device__ __forceinline__ void tower_step(f32x16 (&acc)[4][1], const float *act, const int (&ridx)[4], const uint32_t (&vmask)[4],
+__device__ __forceinline__ void tower_step(f32x16 (&acc)[4][1], const f32x16 (&xin)[4][1], const f32x16 &bv, bool second, const float *act,
+                                           const int (&ridx)[4], const uint32_t (&vmask)[4],
                                            int zero_idx, const float *wq, float4 (&wb)[8], float4 (&xa)[3], const float *&rbase) {
     constexpr TStep st = TowerHolder<GROUP, QPT>::SC.s[I], nx = TowerHolder<GROUP, QPT>::SC.s[I + 2];
     if constexpr ((nx.q & 7) == 0 && I + 2 < TowerSched<GROUP, QPT>::NSTEP)          // step i + 2 opens a new (tap, tile) block
         rbase = tower_abase<G, STRIDE>(act, ridx[nx.tile], vmask[nx.tile], nx.tap, zero_idx);
     xa[(I + 2) % 3] = *reinterpret_cast<const float4 *>(rbase + 8 * nx.q);
+    if constexpr (st.first != 0) {         // the tile's accumulators start here: from block input + bias, or from the bias
+        if (second) acc[st.tile][0] = conv_mma_from(xa[I % 3].x, wb[st.q & 7].x, xin[st.tile][0]);
+        else acc[st.tile][0] = conv_mma(xa[I % 3].x, wb[st.q & 7].x, bv);
+    }
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        acc[st.tile][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(xa[I % 3], k), f4c(wb[st.q & 7], k), acc[st.tile][0], 0, 0, 0);
+    for (int k = st.first != 0 ? 1 : 0; k < 4; ++k)
+        acc[st.tile][0] = conv_mma(f4c(xa[I % 3], k), f4c(wb[st.q & 7], k), acc[st.tile][0]);
     if constexpr (st.last_tile != 0)       // this quad is done for the chunk: its registers take the next chunk's quad
         wb[st.q & 7] = *reinterpret_cast<const float4 *>(wq + (size_t)(st.tap * QPT + st.q + 8) * NT * 64 * 4);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (I + 1 < TowerSched<GROUP, QPT>::NSTEP)
-        tower_step<G, GROUP, QPT, NT, STRIDE, I + 1>(acc, act, ridx, vmask, zero_idx, wq, wb, xa, rbase);
+        tower_step<G, GROUP, QPT, NT, STRIDE, I + 1>(acc, xin, bv, second, act, ridx, vmask, zero_idx, wq, wb, xa, rbase);
 }
 
 // One 3x3 convolution of the tower for the row group GROUP.  wq: this lane's pointer to quad 0 of the layer
 // ([tap][quad][column tile][lane][4]); wb holds the layer's first chunk on entry and the NEXT layer's first on exit.
+// The accumulators need no initialisation: each tile's first MFMA takes its C operand from xin (second = the block's
+// second convolution: block input + bias) or from bv (the bias, the same 16 registers for the four tiles).
 template <class G, int GROUP, int QPT, int NT, int STRIDE>
-__device__ __forceinline__ void tower_layer(f32x16 (&acc)[4][1], const float *act, const int (&ridx)[4], const uint32_t (&vmask)[4],
+__device__ __forceinline__ void tower_layer(f32x16 (&acc)[4][1], const f32x16 (&xin)[4][1], const f32x16 &bv, bool second, const float *act,
+                                            const int (&ridx)[4], const uint32_t (&vmask)[4],
                                             int zero_idx, const float *wq, float4 (&wb)[8]) {
     constexpr TStep s0 = TowerHolder<GROUP, QPT>::SC.s[0], s1 = TowerHolder<GROUP, QPT>::SC.s[1];
     static_assert(s0.tap == s1.tap && s0.tile == s1.tile, "the first two steps share a block");
@@ -331,7 +385,7 @@ __device__ __forceinline__ void tower_layer(f32x16 (&acc)[4][1], const float *ac
     xa[0] = *reinterpret_cast<const float4 *>(rbase + 8 * s0.q);
     xa[1] = *reinterpret_cast<const float4 *>(rbase + 8 * s1.q);
     __builtin_amdgcn_sched_barrier(0);
-    tower_step<G, GROUP, QPT, NT, STRIDE, 0>(acc, act, ridx, vmask, zero_idx, wq, wb, xa, rbase);
+    tower_step<G, GROUP, QPT, NT, STRIDE, 0>(acc, xin, bv, second, act, ridx, vmask, zero_idx, wq, wb, xa, rbase);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -378,7 +432,7 @@ __device__ __forceinline__ void conv_rolled(f32x16 (&acc)[MT][1], const float *a
             else xa[j % 4] = *reinterpret_cast<const float4 *>(act + nbase0 + 8 * (j - BODY));
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(xa[i % 4], k), f4c(wb[q], k), acc[t][0], 0, 0, 0);
+                acc[t][0] = conv_mma(f4c(xa[i % 4], k), f4c(wb[q], k), acc[t][0]);
             if (t == MT - 1) wb[q] = *reinterpret_cast<const float4 *>(wnext + (size_t)q * NT * 64 * 4);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -389,9 +443,8 @@ __device__ __forceinline__ void conv_rolled(f32x16 (&acc)[MT][1], const float *a
     }
 }
 
-// C/D layout of v_mfma_f32_32x32x2_f32: register v of lane l holds
-//   row = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5),  col = l & 31
-__device__ __forceinline__ int cd_row(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
+// (C/D layout of v_mfma_f32_32x32x2_f32: register v of lane l holds row (v & 3) + 8 * (v >> 2) + 4 * (l >> 5), column
+// l & 31 -- with the weights on the A side the row is the output channel and the column the board cell: conv_mma above)
 
 template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4, bool TR = false, bool FUSED = false>
 __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 && NT <= 2 ? 3 : (RW * CW == 16 ? 1 : (RW * CW > 8 ? RW * CW / 4 : (RW * CW == 8 && RW * MT == 8 ? 1 : 2))))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs, int bstride,
@@ -489,11 +542,9 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            const float bias = P.stem_b[col0 + nt * 32 + (lane & 31)];
+            const f32x16 bias = channel_vec(P.stem_b + col0 + nt * 32, half);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[mt][nt][v] = bias;
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bias;
         }
         // the 27 binary inputs of a row (K index kk = tap * 3 + plane: empty / mine / theirs at the tapped cell), once per tile
         uint32_t inbits[MT];
@@ -521,24 +572,30 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], w[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = conv_mma(a[mt], w[nt], acc[mt][nt]);
         }
+        // xres = the block input PLUS the bias of the block's second convolution, whose accumulators start from it
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int nt = 0; nt < NTW; ++nt) {
+            const f32x16 b2 = channel_vec(P.conv_b + (size_t)P.conv_b_stride + col0 + nt * 32, half);
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x16 o;
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float o = fmaxf(acc[mt][nt][v], 0.0f);
-                    xres[mt][nt][v] = o;
-                    act[lds_row(wave * WROWS + mt * 32 + cd_row(v, lane)) * STRIDE + col0 + nt * 32 + (lane & 31)] = o;
-                }
+                for (int v = 0; v < 16; ++v) o[v] = relu(acc[mt][nt][v]);
+                store_tile(act + ridx[mt] + col0 + nt * 32, o);
+                xres[mt][nt] = o + b2;
+            }
+        }
     }
     __syncthreads();
     STAMP(2);
     if constexpr (TR) { if (tid == 0) P.dbg[(size_t)blockIdx.x * 64 + 56] = __builtin_amdgcn_s_memtime(); }   // core-clock counter
 
     // ---- residual blocks (ResBlock.forward resnet.py:21-27) -----------------------------------------
+    f32x16 bv[NTW];                                // the bias of the next layer, fetched one layer ahead
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) bv[nt] = channel_vec(P.conv_b + col0 + nt * 32, half);
     float4 wb[WBN];                                // STATIC_TOWER / ROLLED: the current chunk of weight quads (tower_layer, conv_rolled)
     if constexpr (STATIC_TOWER || ROLLED) {
         const float *wq0 = P.conv_w4 + ((size_t)wc * 64 + lane) * 4;
@@ -549,23 +606,41 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
         const bool second = layer & 1;
         const float *wl = P.conv_w + (size_t)layer * P.conv_w_stride;
         const float *bl = P.conv_b + (size_t)layer * P.conv_b_stride;
+        // Biases are fetched ahead where a wave owns ONE column tile (16 registers): the next layer's while this layer's
+        // last MFMAs drain (bv: what a block's first convolution starts from), and -- except in the statically scheduled
+        // kernels, which have no registers to spare across the barrier -- the bias after that, which is folded into the
+        // block input kept in xres.
+        constexpr bool AHEAD = NTW == 1;
+        const int nl = 2 * P.blocks;
+        if constexpr (!STATIC_TOWER) {
+            if (second) {                              // x += residual: the accumulators start from block input + bias
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const float bias = bl[col0 + nt * 32 + (lane & 31)];
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = xres[mt][nt];
+            } else {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc[mt][nt][v] = second ? xres[mt][nt][v] + bias : bias;   // x += residual
+                for (int nt = 0; nt < NTW; ++nt) {
+                    if constexpr (!AHEAD) bv[nt] = channel_vec(bl + col0 + nt * 32, half);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv[nt];
+                }
+            }
         }
         if constexpr (STATIC_TOWER) {
             const float *wq = P.conv_w4 + (size_t)layer * P.conv_w_stride + ((size_t)wc * 64 + lane) * 4;
-            if (wave == 0) tower_layer<G, 0, S / 4, NT, STRIDE>(acc, act, ridx, vmask, ZERO_IDX + 4 * half, wq, wb);
-            else tower_layer<G, 1, S / 4, NT, STRIDE>(acc, act, ridx, vmask, ZERO_IDX + 4 * half, wq, wb);
+            if (wave == 0) tower_layer<G, 0, S / 4, NT, STRIDE>(acc, xres, bv[0], second, act, ridx, vmask, ZERO_IDX + 4 * half, wq, wb);
+            else tower_layer<G, 1, S / 4, NT, STRIDE>(acc, xres, bv[0], second, act, ridx, vmask, ZERO_IDX + 4 * half, wq, wb);
         } else if constexpr (ROLLED) {
             const float *wq = P.conv_w4 + (size_t)layer * P.conv_w_stride + ((size_t)wc * 64 + lane) * 4;
             conv_rolled<G, MT, S / 4, NT, STRIDE>(acc, act, ridx, vmask, ZERO_IDX + 4 * half, wq, wb);
         } else {
             conv_mfma<G, MT, NTW, 9, S, PF, NT, SK>(acc, wl + wc * NTW, act, ridx, vmask, STRIDE, ZERO_IDX + 4 * half, lane, need);
+        }
+        f32x16 b2[NTW];
+        if constexpr (AHEAD) {
+            bv[0] = channel_vec(bl + (size_t)(layer + 1 < nl ? P.conv_b_stride : 0) + col0, half);
+            if constexpr (!STATIC_TOWER) { if (second && layer + 2 < nl) b2[0] = channel_vec(bl + 2 * (size_t)P.conv_b_stride + col0, half); }
         }
         if (layer < 16) STAMP(3 + 3 * layer);
         __syncthreads();                               // every wave is done reading the layer input
@@ -573,13 +648,19 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
+            for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float o = fmaxf(acc[mt][nt][v], 0.0f);
-                    if (second) xres[mt][nt][v] = o;
-                    act[lds_row(wave * WROWS + mt * 32 + cd_row(v, lane)) * STRIDE + col0 + nt * 32 + (lane & 31)] = o;
-                }
+                for (int v = 0; v < 16; ++v) acc[mt][nt][v] = relu(acc[mt][nt][v]);
+                store_tile(act + ridx[mt] + col0 + nt * 32, acc[mt][nt]);
+            }
+        if (second && layer + 2 < nl) {                // the next block's input + the bias of its second convolution
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                if constexpr (!AHEAD || STATIC_TOWER) b2[nt] = channel_vec(bl + 2 * (size_t)P.conv_b_stride + col0 + nt * 32, half);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xres[mt][nt] = acc[mt][nt] + b2[nt];
+            }
+        }
         __syncthreads();
         if (layer < 16) STAMP(5 + 3 * layer);
     }
@@ -600,11 +681,10 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     int pridx[PMT];
     uint32_t pvmask[PMT], pneed[PMT];
     {
-        const float bp = P.pol_b[lane & 31];
+        const f32x16 bp = channel_vec(P.pol_b, half);
 #pragma unroll
         for (int i = 0; i < PMT; ++i) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) accp[i][0][v] = bp;
+            accp[i][0] = bp;
             pridx[i] = ridx[0]; pvmask[i] = vmask[0]; pneed[i] = need[0];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) if (mt == pt0 + i) { pridx[i] = ridx[mt]; pvmask[i] = vmask[mt]; pneed[i] = need[mt]; }
@@ -712,13 +792,14 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     STAMP(52);
     __syncthreads();
     // policy-head activations over the (now dead) tower activations, value-head ones beside them
+    if (pol_here) {
 #pragma unroll
-    for (int i = 0; i < PMT; ++i)
+        for (int i = 0; i < PMT; ++i) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int row = lds_row(wave * WROWS + (pt0 + i) * 32 + cd_row(v, lane));
-            if (pol_here) act[row * STRIDE + (lane & 31)] = fmaxf(accp[i][0][v], 0.0f);
+            for (int v = 0; v < 16; ++v) accp[i][0][v] = relu(accp[i][0][v]);
+            store_tile(act + pridx[i], accp[i][0]);
         }
+    }
     if (!VMFMA && tid < TB * CELLS) {
         hval[tid * 4 + 0] = fmaxf(hv0, 0.0f);
         hval[tid * 4 + 1] = fmaxf(hv1, 0.0f);

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--f16", action="store_true")
     ap.add_argument("--game", choices=["connect4", "gomoku9"], default="connect4")
+    ap.add_argument("--digest", action="store_true", help="also print a SHA-256 of the outputs' bytes (A/B of two builds: same bits?)")
     a = ap.parse_args()
     import torch
     from azsp.model import ResNet
@@ -41,7 +42,7 @@ def main():
             boards[:] = rng.choice([-1, 0, 0, 0, 1], size=boards.shape)
         with Engine(a.game, B, 1, res_blocks=a.blocks, channels=a.channels, timing=True, f16_split=a.f16) as e:
             e.load_resnet(blob)
-            e.predict(boards)
+            out = e.predict(boards)
             e.reset_stats()
             for _ in range(a.reps):
                 e.predict(boards)
@@ -53,6 +54,12 @@ def main():
         if flops:
             line["tflops"] = round(B * flops / ms / 1e9, 1)
             line["frac_fp32_peak"] = round(B * flops / ms / 1e9 / 157.3, 3)
+        if a.digest:
+            import hashlib
+            h = hashlib.sha256()
+            for x in out:
+                h.update(np.ascontiguousarray(x).tobytes())
+            line["sha256_16"] = h.hexdigest()[:16]
         print(line, flush=True)
 
 
