@@ -60,10 +60,28 @@ struct ResNet16Dev {
     int32_t *d_perm = nullptr;          // [4][256]: row orders for WR = 1, 2, 4, 8
 };
 
-__device__ __forceinline__ int cd_row16(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+// C/D layout of the 32x32 MFMAs: register v of lane l holds row (v & 3) + 8 * (v >> 2) + 4 * (l >> 5), column l & 31.
+// The convolutions put the WEIGHTS on the A side and the activations on the B side (both operands have the same lane
+// layout), so the row is the output channel within the column tile and the column the board cell: a lane's 16 results
+// are ONE cell x four runs of four consecutive channels, which the epilogue converts and stores four at a time
+// (8-byte LDS writes per plane at the lane's own row) -- as in the fp32 kernel (conv_mma, azsp_resnet_kernel.h).
+__device__ __forceinline__ int cd_ch16(int v, int lane) { return (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ f32x16 mfma16(h8 a_act, h8 b_w, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(b_w, a_act, c, 0, 0, 0);
+}
+// the 16 per-channel constants of a lane for the column tile whose channel 0 is at b
+__device__ __forceinline__ f32x16 channel_vec16(const float *b, int half) {
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 t = *reinterpret_cast<const float4 *>(b + 8 * i + 4 * half);
+        r[4 * i] = t.x; r[4 * i + 1] = t.y; r[4 * i + 2] = t.z; r[4 * i + 3] = t.w;
+    }
+    return r;
 }
 
 // conv over the LDS-resident split activations for NTILE row tiles of this wave and ONE column tile.
@@ -292,8 +310,8 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     for (int i = tid; i < F16_ROWS; i += NTHREADS) s_perm[i] = P.perm[i];
     __syncthreads();
 
-    auto row_geom = [&](int g, uint32_t &vm, int &ab) {     // g = GEMM row
-        const int r = s_perm[g];
+    auto row_geom = [&](int g, uint32_t &vm, int &ab, int &r) {     // g = GEMM row; r = its board-cell row in LDS
+        r = s_perm[g];
         const int b = r / CELLS, pos = r % CELLS, y = pos / COLS, x = pos % COLS;
         const bool real = r < TB * CELLS && board0 + b < n_leaf;
         uint32_t m = 0;
@@ -310,42 +328,47 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         for (int t = 0; t < 9; ++t) if (__ballot((vm >> t) & 1u)) nd |= 1u << t;
         return nd;
     };
-    int abyte[MT];
+    int abyte[MT], lrow[MT];
     uint32_t vmask[MT], need[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        row_geom(wr * (MT * 32) + mt * 32 + r32, vmask[mt], abyte[mt]);
+        row_geom(wr * (MT * 32) + mt * 32 + r32, vmask[mt], abyte[mt], lrow[mt]);
         need[mt] = need_of(vmask[mt]);
     }
 
     f32x16 acc[MT], xres[MT];
-    const int col = wc * 32 + r32;                                // output channel of this lane
+    const int ch0 = wc * 32;                                      // first output channel of this wave's column tile
 
-    // writes relu(acc*inv) as split fp16 planes (scaled by 2^ACT_SHIFT); optionally keeps the fp32 copy
+    // writes relu(acc*inv) as split fp16 planes (scaled by 2^ACT_SHIFT); optionally keeps the fp32 copy.  inv is a power
+    // of two, so scaling by inv * 2^ACT_SHIFT first and taking the fp32 copy back by 2^-ACT_SHIFT rounds nowhere.
     auto store_act = [&](const f32x16 (&a)[MT], float inv, bool keep) {
+        const float inv_s = inv * ACT_SCALE;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
+            unsigned char *dst = smem16 + lrow[mt] * ROW_BYTES + (ch0 + 4 * half) * 2;     // + 16 bytes per run of four channels
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const float o = fmaxf(a[mt][v] * inv, 0.0f);
-                if (keep) xres[mt][v] = o;
-                const float as = fminf(o * ACT_SCALE, 65504.0f);
-                const _Float16 hi = (_Float16)as;
-                const _Float16 lo = (_Float16)(as - (float)hi);
-                const int idx = s_perm[wr * (MT * 32) + mt * 32 + cd_row16(v, lane)] * RS + col;
-                if ((ABL & 4) && v > 0) continue;
-                act_hi[idx] = hi;
-                act_lo[idx] = lo;
+            for (int i = 0; i < 4; ++i) {
+                f32x4v as;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = fmaxf(a[mt][4 * i + j] * inv_s, 0.0f);
+                    if (keep) xres[mt][4 * i + j] = t * (1.0f / ACT_SCALE);
+                    as[j] = fminf(t, 65504.0f);
+                }
+                const h4 hi = __builtin_convertvector(as, h4);
+                const h4 lo = __builtin_convertvector(as - __builtin_convertvector(hi, f32x4v), h4);
+                if ((ABL & 4) && i > 0) continue;
+                *reinterpret_cast<h4 *>(dst + 16 * i) = hi;
+                *reinterpret_cast<h4 *>(dst + 16 * i + PLANE_BYTES) = lo;
             }
+        }
     };
 
     // ---- stem: A fragments straight from the bitboards (values 0 / 2^ACT_SHIFT: lo plane is zero) ------
     {
-        const float bias = P.stem_b[col];
+        const f32x16 bias = channel_vec16(P.stem_b + ch0, half);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[mt][v] = bias;
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = bias;
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
             const h8 *wp = P.stem_w + ((size_t)sl * CT + wc) * 2 * 64 + lane;
@@ -393,12 +416,12 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     }
     for (int layer = 0; layer < 2 * P.blocks; ++layer) {
         const bool second = layer & 1;
-        const float bias = P.conv_b[(size_t)layer * P.conv_b_stride + col];
+        const f32x16 bias = channel_vec16(P.conv_b + (size_t)layer * P.conv_b_stride + ch0, half);
         const float up = P.conv_up[layer];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[mt][v] = second ? fmaf(xres[mt][v], up, bias) : bias;
+            for (int v = 0; v < 16; ++v) acc[mt][v] = second ? fmaf(xres[mt][v], up, bias[v]) : bias[v];
         if constexpr (STATIC16) {
             const h8 *wq = P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64 + lane;
             const int zb = ZERO_BYTE + half * 16;
@@ -421,19 +444,19 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     // ---- heads: policy 1x1 and value 3x3 convs, one 32-wide column tile each; the row tiles of a row
     //      group are dealt round-robin to its CT waves -----------------------------------------------------
     f32x16 accp[PT], accv[PT];
-    int hbyte[PT], hrow0[PT];
+    int hbyte[PT], hrow0[PT], hrow[PT];
     uint32_t hmask[PT], hneed[PT];
     {
-        const float bp = P.pol_b[r32], bv = P.val_b[r32];
+        const f32x16 bp = channel_vec16(P.pol_b, half), bv = channel_vec16(P.val_b, half);
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
             const int mt = wc + i * CT;
             hrow0[i] = mt < MT ? wr * (MT * 32) + mt * 32 : -1;
-            row_geom(hrow0[i] < 0 ? F16_ROWS - 1 : hrow0[i] + r32, hmask[i], hbyte[i]);
+            row_geom(hrow0[i] < 0 ? F16_ROWS - 1 : hrow0[i] + r32, hmask[i], hbyte[i], hrow[i]);
             if (hrow0[i] < 0) hmask[i] = 0;
             hneed[i] = need_of(hmask[i]);
-#pragma unroll
-            for (int v = 0; v < 16; ++v) { accp[i][v] = bp; accv[i][v] = bv; }
+            accp[i] = bp;
+            accv[i] = bv;
         }
     }
     conv16s<G, PT, 1, SL, 1>(accp, P.pol_w, plane_hi, PLANE_BYTES, hbyte, hmask, hneed, ROW_BYTES, ZERO_BYTE + half * 16, lane);
@@ -446,9 +469,9 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         if (hrow0[i] >= 0) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int row = s_perm[hrow0[i] + cd_row16(v, lane)];     // s_perm lies beyond the head buffers
-                hb[row * HB_STRIDE + r32] = fmaxf(accp[i][v] * P.pol_inv, 0.0f);
-                if (r32 < VAL_CH) hb[row * HB_STRIDE + POL_CH + r32] = fmaxf(accv[i][v] * P.val_inv, 0.0f);
+                const int ch = cd_ch16(v, lane);                          // the lane's cell is row hrow[i]
+                hb[hrow[i] * HB_STRIDE + ch] = fmaxf(accp[i][v] * P.pol_inv, 0.0f);
+                if (ch < VAL_CH) hb[hrow[i] * HB_STRIDE + POL_CH + ch] = fmaxf(accv[i][v] * P.val_inv, 0.0f);
             }
         }
     __syncthreads();
