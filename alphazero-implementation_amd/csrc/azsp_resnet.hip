@@ -122,7 +122,7 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
     n->o_fcp_b = reserve(g.AP);
     n->o_fcv_w = reserve((size_t)VAL_CH * g.cells);
     n->o_fcv_b = reserve(4);
-    off += (size_t)8 * 8 * 64 * 4;          // slack: the weight streams prefetch one block / chunk past their array
+    off += (size_t)2 * 8 * 8 * 64 * 4;      // slack: the weight streams prefetch one block / chunk past their array
     n->blob_floats = off;
     if (hipMalloc((void **)&n->d_blob, off * sizeof(float)) != hipSuccess) { delete n; return nullptr; }
     if (game == 0) {
@@ -175,7 +175,21 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
         ConvBN c = take_conv_bn(p, g.C, g.C, 3);
         fold(c, w, b);
         permute_conv(w, g.C, g.C, 3, g.S, g.NT, host.data() + n->o_conv_w + (size_t)l * n->conv_w_stride);
-        if (n->has_w4) {            // [tap][s / 4][nt][lane][s & 3] from [tap][s][lane][nt]
+        if (n->has_w4 && n->game == 2) {
+            // 16-row-tile tower (conv_tile16): [tap][16-channel input group][16-channel output tile][lane][4] with
+            // lane = (output channel & 15) + 16 * quarter, element j = input channel 16 * group + 4 * quarter + j
+            float *dst = host.data() + n->o_conv_w4 + (size_t)l * n->conv_w_stride;
+            const int G16 = g.Cp / 16;
+            for (int tap = 0; tap < 9; ++tap)
+                for (int sg = 0; sg < G16; ++sg)
+                    for (int ct = 0; ct < G16; ++ct)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j) {
+                                const int o = ct * 16 + (lane & 15), i = 16 * sg + 4 * (lane >> 4) + j;
+                                dst[((((size_t)tap * G16 + sg) * G16 + ct) * 64 + lane) * 4 + j] =
+                                    (o < g.C && i < g.C) ? w[((size_t)o * g.C + i) * 9 + tap] : 0.0f;
+                            }
+        } else if (n->has_w4) {     // [tap][s / 4][nt][lane][s & 3] from [tap][s][lane][nt]
             const float *src = host.data() + n->o_conv_w + (size_t)l * n->conv_w_stride;
             float *dst = host.data() + n->o_conv_w4 + (size_t)l * n->conv_w_stride;
             for (int tap = 0; tap < 9; ++tap)

@@ -443,6 +443,83 @@ __device__ __forceinline__ void conv_rolled(f32x16 (&acc)[MT][1], const float *a
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 16-row tiles for one 9x9 board per workgroup (Gomoku, 96 channels and more)
+// ------------------------------------------------------------------------------------------------
+// 81 cells in 32-row tiles are 96 GEMM rows: 15 of them padding, 16 % of the matrix-pipe time.  v_mfma_f32_16x16x4_f32 has
+// the same FLOP rate as the 32x32x2 form (32 cycles, tools/probe/mfma16x16.hip), so the tower runs on FIVE 16-row tiles
+// (cells 0..79) and the last cell (the bottom-right corner: four of its nine taps exist) on the vector ALU of the same
+// waves -- 8 FMAs beside 40 MFMAs per 16 input channels, with the weights the MFMAs already hold:
+//   A side: weights, lane l = output channel (l & 15) of a 16-channel tile, input channels 4 * (l >> 4) + j of the 16-group
+//   B side: activations, lane l = cell (l & 15) of the row tile, the same input channels (one 16-byte LDS read = 4 MFMAs)
+//   D: register j of lane l = output channel 4 * (l >> 4) + j of the tile, cell l & 15  -> one 16-byte store per tile
+// A wave owns 32 output channels (two 16-channel tiles) x all five row tiles; the corner cell's lane (oc, kq) sums the
+// products of its quarter of the input channels, the four quarters are added across lanes at the end of the layer.
+// Same rolled software pipeline as conv_rolled: chunks of QC 16-channel groups, a body of 6 * QC steps (tile-major, the
+// corner cell as a sixth "tile"), activations two steps ahead, the chunk's last user reloads each weight pair in place.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4m conv_mma16(float a_act, float w, const f32x4m &c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(w, a_act, c, 0, 0, 0);
+}
+template <int SPT> struct Tile16Geo { static constexpr int QC = SPT % 8 == 0 ? 8 : (SPT % 6 == 0 ? 6 : SPT); };
+constexpr uint32_t G9_CORNER_TAPS = 0x1Bu;            // taps (dy, dx) in {-1, 0}^2 exist for the cell (8, 8): bits 0, 1, 3, 4
+
+template <class G, int SPT, int NT, int STRIDE>
+__device__ __forceinline__ void conv_tile16(f32x4m (&acc)[5][2], float (&vacc)[2], const float *act, const int (&ridx)[5],
+                                            const uint32_t (&vmask)[5], int r80, int zero_idx, const float *wq,
+                                            float4 (&wb)[Tile16Geo<SPT>::QC][2]) {
+    constexpr int QC = Tile16Geo<SPT>::QC, CPT = SPT / QC, NCHUNK = 9 * CPT, BODY = 6 * QC;
+    constexpr size_t QSTR = (size_t)2 * NT * 64 * 4;                  // floats between consecutive 16-channel groups
+    static_assert(SPT % QC == 0 && BODY % 4 == 0, "chunking");
+    float4 xa[4];
+    int base[6];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) base[t] = tower_aindex<G, STRIDE>(ridx[t], vmask[t], 0, zero_idx);
+    base[5] = tower_aindex<G, STRIDE>(r80, G9_CORNER_TAPS, 0, zero_idx);
+    xa[0] = *reinterpret_cast<const float4 *>(act + base[0]);
+    xa[1] = *reinterpret_cast<const float4 *>(act + base[0] + 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int cn = c + 1 < NCHUNK ? c + 1 : c;
+        const int tap = c / CPT, tapn = cn / CPT, q0n = (cn % CPT) * QC;
+        const int nbase0 = tower_aindex<G, STRIDE>(ridx[0], vmask[0], tapn, zero_idx) + 16 * q0n;
+        const int q0 = (c % CPT) * QC;
+        const bool corner = (G9_CORNER_TAPS >> tap) & 1u;             // this tap exists for the corner cell
+        const float *wnext = wq + (size_t)(c * QC + QC) * QSTR;       // group 0 of the next chunk
+#pragma unroll
+        for (int i = 0; i < BODY; ++i) {
+            const int t = i / QC, q = i % QC;
+            const int j = i + 2;                                      // the step whose activations are requested now
+            if (j < BODY) xa[j % 4] = *reinterpret_cast<const float4 *>(act + base[j / QC] + 16 * (q0 + j % QC));
+            else xa[j % 4] = *reinterpret_cast<const float4 *>(act + nbase0 + 16 * (j - BODY));
+            if (t < 5) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[t][0] = conv_mma16(f4c(xa[i % 4], k), f4c(wb[q][0], k), acc[t][0]);
+                    acc[t][1] = conv_mma16(f4c(xa[i % 4], k), f4c(wb[q][1], k), acc[t][1]);
+                }
+            } else {
+                if (corner) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        vacc[0] = fmaf(f4c(xa[i % 4], k), f4c(wb[q][0], k), vacc[0]);
+                        vacc[1] = fmaf(f4c(xa[i % 4], k), f4c(wb[q][1], k), vacc[1]);
+                    }
+                }
+                wb[q][0] = *reinterpret_cast<const float4 *>(wnext + (size_t)q * QSTR);
+                wb[q][1] = *reinterpret_cast<const float4 *>(wnext + (size_t)q * QSTR + 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (cn != c && cn % CPT == 0) {                               // the next chunk opens a new tap
+#pragma unroll
+            for (int t = 0; t < 5; ++t) base[t] = tower_aindex<G, STRIDE>(ridx[t], vmask[t], tapn, zero_idx);
+            base[5] = tower_aindex<G, STRIDE>(r80, G9_CORNER_TAPS, tapn, zero_idx);
+        }
+    }
+}
+
 // (C/D layout of v_mfma_f32_32x32x2_f32: register v of lane l holds row (v & 3) + 8 * (v >> 2) + 4 * (l >> 5), column
 // l & 31 -- with the weights on the A side the row is the output channel and the column the board cell: conv_mma above)
 
@@ -465,8 +542,11 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     // the statically scheduled tower (tower_layer): 6-board workgroups on the 2 x CW wave grid, 64 or 128 channels
     constexpr bool STATIC_TOWER = SK && MT == 4 && RW == 2 && CW == NT && (NT == 2 || NT == 4);
     // every other wave grid with one column tile per wave: the rolled form of the same software pipeline (conv_rolled)
-    constexpr bool ROLLED = !STATIC_TOWER && PF == 0 && CW == NT && NT >= 2;
+    // one 9x9 board per workgroup from 96 channels on: the tower on five 16-row tiles + the corner cell (conv_tile16)
+    constexpr bool TILE16 = std::is_same<G, Gomoku9>::value && PF == 0 && CW == NT && RW == 1 && MT == 3 && NT >= 3;
+    constexpr bool ROLLED = !STATIC_TOWER && !TILE16 && PF == 0 && CW == NT && NT >= 2;
     constexpr int WBN = ROLLED ? RolledGeo<S / 4>::QC : 8;
+    constexpr int SPT16 = CP / 16, QC16 = Tile16Geo<SPT16>::QC;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *act = smem;                             // [WG_ROWS + 1][STRIDE], 16-byte aligned rows
     constexpr int AP = G::AP;                      // actions padded to a multiple of 8
@@ -596,6 +676,46 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     f32x16 bv[NTW];                                // the bias of the next layer, fetched one layer ahead
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) bv[nt] = channel_vec(P.conv_b + col0 + nt * 32, half);
+    // TILE16 state: lane l = cell (l & 15) of a 16-row tile / output channel (l & 15) of a 16-channel tile, quarter kq
+    const int kq = lane >> 4, l15 = lane & 15;
+    int ridx16[5];
+    uint32_t vmask16[5];
+    f32x4m acc16[5][2], xres16[5][2];
+    float vacc[2], xresv[2];                       // the corner cell (80): this lane's partial sum, block input + bias
+    float4 wb16[TILE16 ? QC16 : 1][2];
+    constexpr int R80 = 80 * STRIDE;
+    if constexpr (TILE16) {
+        static_assert(TB == 1 && CELLS == 81, "one 9x9 board per workgroup");
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int pos = 16 * t + l15, y = pos / COLS, x = pos % COLS;
+            uint32_t m = 0;
+            for (int tp = 0; tp < 9; ++tp) {
+                const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                if (yy >= 0 && yy < ROWS && xx >= 0 && xx < COLS) m |= 1u << tp;
+            }
+            vmask16[t] = m;
+            ridx16[t] = pos * STRIDE + 4 * kq;
+        }
+        // block input (+ the bias of the block's second convolution) in the tower's register layout, from what the stem stored
+        const float *b2 = P.conv_b + (size_t)P.conv_b_stride + col0;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const float4 bq = *reinterpret_cast<const float4 *>(b2 + 16 * ct + 4 * kq);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const float4 x = *reinterpret_cast<const float4 *>(act + ridx16[t] + col0 + 16 * ct);
+                xres16[t][ct] = (f32x4m){x.x + bq.x, x.y + bq.y, x.z + bq.z, x.w + bq.w};
+            }
+            xresv[ct] = act[R80 + col0 + 16 * ct + l15] + b2[16 * ct + l15];
+        }
+        const float *wq0 = P.conv_w4 + ((size_t)(2 * wc) * 64 + lane) * 4;
+#pragma unroll
+        for (int j = 0; j < QC16; ++j) {
+            wb16[j][0] = *reinterpret_cast<const float4 *>(wq0 + (size_t)j * 2 * NT * 64 * 4);
+            wb16[j][1] = *reinterpret_cast<const float4 *>(wq0 + (size_t)j * 2 * NT * 64 * 4 + 256);
+        }
+    }
     float4 wb[WBN];                                // STATIC_TOWER / ROLLED: the current chunk of weight quads (tower_layer, conv_rolled)
     if constexpr (STATIC_TOWER || ROLLED) {
         const float *wq0 = P.conv_w4 + ((size_t)wc * 64 + lane) * 4;
@@ -606,6 +726,54 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
         const bool second = layer & 1;
         const float *wl = P.conv_w + (size_t)layer * P.conv_w_stride;
         const float *bl = P.conv_b + (size_t)layer * P.conv_b_stride;
+        if constexpr (TILE16) {
+            const float *blc = bl + col0;
+            const bool fold = second && layer + 2 < 2 * P.blocks;      // a next block exists: keep its input + bias
+            // the accumulators start from block input + bias (second convolution of a block) or from the bias; the
+            // corner cell's sum is split over the four lanes (oc, kq): quarter 0 takes the start value
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                if (second) {
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) acc16[t][ct] = xres16[t][ct];
+                    vacc[ct] = kq == 0 ? xresv[ct] : 0.0f;
+                } else {
+                    const float4 bq = *reinterpret_cast<const float4 *>(blc + 16 * ct + 4 * kq);
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) acc16[t][ct] = (f32x4m){bq.x, bq.y, bq.z, bq.w};
+                    vacc[ct] = kq == 0 ? blc[16 * ct + l15] : 0.0f;
+                }
+            }
+            const float *wq = P.conv_w4 + (size_t)layer * P.conv_w_stride + ((size_t)(2 * wc) * 64 + lane) * 4;
+            conv_tile16<G, SPT16, NT, STRIDE>(acc16, vacc, act, ridx16, vmask16, R80 + 4 * kq, ZERO_IDX + 4 * kq, wq, wb16);
+            float4 b2q[2];
+            float b2s[2];
+            if (fold) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    b2q[ct] = *reinterpret_cast<const float4 *>(blc + 2 * (size_t)P.conv_b_stride + 16 * ct + 4 * kq);
+                    b2s[ct] = blc[2 * (size_t)P.conv_b_stride + 16 * ct + l15];
+                }
+            }
+            __syncthreads();                           // every wave is done reading the layer input
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    const float4 o = make_float4(relu(acc16[t][ct][0]), relu(acc16[t][ct][1]), relu(acc16[t][ct][2]), relu(acc16[t][ct][3]));
+                    *reinterpret_cast<float4 *>(act + ridx16[t] + col0 + 16 * ct) = o;
+                    if (fold) xres16[t][ct] = (f32x4m){o.x + b2q[ct].x, o.y + b2q[ct].y, o.z + b2q[ct].z, o.w + b2q[ct].w};
+                }
+                float v = vacc[ct];                    // the corner cell: the four quarters of the input channels
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                v = relu(v);
+                if (kq == 0) act[R80 + col0 + 16 * ct + l15] = v;
+                if (fold) xresv[ct] = v + b2s[ct];
+            }
+            __syncthreads();
+            continue;
+        }
         // Biases are fetched ahead where a wave owns ONE column tile (16 registers): the next layer's while this layer's
         // last MFMAs drain (bv: what a block's first convolution starts from), and -- except in the statically scheduled
         // kernels, which have no registers to spare across the barrier -- the bias after that, which is folded into the
