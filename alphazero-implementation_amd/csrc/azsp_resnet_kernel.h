@@ -109,7 +109,7 @@ struct LdsLayout {
     static constexpr int LOGITS = (WG_ROWS + 1) * STRIDE;      // after act[WG_ROWS + 1][STRIDE] (last row = zeros)
     static constexpr int VL = LOGITS + TB * G::AP;
     static constexpr int HVAL = VL + ((TB + 7) & ~7);
-    static constexpr int PERM = HVAL + WG_ROWS * 4;
+    static constexpr int PERM = HVAL + WG_ROWS * (std::is_same<G, Gomoku9>::value ? 16 : 4);   // (9x9: + the value conv's channel slices)
     static constexpr int PART = PERM + WG_ROWS;
     static constexpr int TOTAL = PART + (PART_ALIAS ? 0 : WG_ROWS * 8);
 };
@@ -746,6 +746,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
             }
             const float *wq = P.conv_w4 + (size_t)layer * P.conv_w_stride + ((size_t)(2 * wc) * 64 + lane) * 4;
             conv_tile16<G, SPT16, NT, STRIDE>(acc16, vacc, act, ridx16, vmask16, R80 + 4 * kq, ZERO_IDX + 4 * kq, wq, wb16);
+            if (layer < 16) STAMP(3 + 3 * layer);
             float4 b2q[2];
             float b2s[2];
             if (fold) {
@@ -772,6 +773,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
                 if (fold) xresv[ct] = v + b2s[ct];
             }
             __syncthreads();
+            if (layer < 16) STAMP(5 + 3 * layer);
             continue;
         }
         // Biases are fetched ahead where a wave owns ONE column tile (16 registers): the next layer's while this layer's
@@ -920,6 +922,48 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
 #pragma unroll
             for (int i = 0; i < 4; ++i) hval[(rb + i) * 4 + j] = fmaxf(av[i], 0.0f);   // hval is not read before the barriers below
         }
+    } else if constexpr (std::is_same<G, Gomoku9>::value && (NTHREADS / (TB * CELLS) >= 2)) {
+        // 9x9 boards, one per workgroup: the input channels of a cell are split over VS threads (one slice each, the same
+        // three chains per kernel row inside a slice); the slices are added in order below, after the barrier
+        constexpr int VS = NTHREADS / (TB * CELLS) >= 4 ? 4 : 2, CSL = CP / VS;
+        static_assert(CSL % 4 == 0, "channel slices are whole 16-byte reads");
+        if (tid < VS * TB * CELLS) {
+            const int cell = tid % (TB * CELLS), vs = tid / (TB * CELLS);
+            const int pos = cell % CELLS, y = pos / COLS, x = pos % COLS;
+            const bool real = board0 + cell / CELLS < n_leaf;
+            float hr[3][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+            for (int dx = 0; dx < 3; ++dx) {
+                const float *xr[3], *wv[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int yy = y + dy - 1, xx = x + dx - 1;
+                    const bool ok = real && yy >= 0 && yy < ROWS && xx >= 0 && xx < COLS;
+                    xr[dy] = act + (ok ? (cell + (dy - 1) * COLS + (dx - 1)) * STRIDE : ZERO_IDX) + vs * CSL;
+                    wv[dy] = P.val_w + ((size_t)(dy * 3 + dx) * CP + vs * CSL) * 4;
+                }
+#pragma unroll 2
+                for (int c4 = 0; c4 < CSL; c4 += 4) {
+                    float4 x[3];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) x[dy] = *reinterpret_cast<const float4 *>(xr[dy] + c4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const float a = j == 0 ? x[dy].x : (j == 1 ? x[dy].y : (j == 2 ? x[dy].z : x[dy].w));
+                            const float4 w = *reinterpret_cast<const float4 *>(wv[dy] + (c4 + j) * 4);
+                            hr[dy][0] = fmaf(a, w.x, hr[dy][0]);
+                            hr[dy][1] = fmaf(a, w.y, hr[dy][1]);
+                            hr[dy][2] = fmaf(a, w.z, hr[dy][2]);
+                        }
+                }
+            }
+            float *dst = hval + (size_t)(vs * TB * CELLS + cell) * 4;      // slice vs of the cell; summed after the barrier
+            static_assert(VS * TB * CELLS * 4 <= L::PERM - L::HVAL, "the slices fit the hval region");
+            dst[0] = (hr[0][0] + hr[1][0]) + hr[2][0];
+            dst[1] = (hr[0][1] + hr[1][1]) + hr[2][1];
+            dst[2] = (hr[0][2] + hr[1][2]) + hr[2][2];
+        }
     } else if (tid < TB * CELLS) {
         // other wave grids: one thread per board cell on the vector ALU, weights wave-uniform; the SAME three
         // fma chains (one per kernel row, bias in the first, summed (r0 + r1) + r2) as the MFMA form, so that every
@@ -966,6 +1010,17 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
 #pragma unroll
             for (int v = 0; v < 16; ++v) accp[i][0][v] = relu(accp[i][0][v]);
             store_tile(act + pridx[i], accp[i][0]);
+        }
+    }
+    if constexpr (!VMFMA && std::is_same<G, Gomoku9>::value && (NTHREADS / (TB * CELLS) >= 2)) {
+        constexpr int VS = NTHREADS / (TB * CELLS) >= 4 ? 4 : 2;
+        if (tid < TB * CELLS) {                    // bias + the channel slices in order (a thread overwrites only its own slice 0)
+            hv0 = P.val_b[0]; hv1 = P.val_b[1]; hv2 = P.val_b[2];
+#pragma unroll
+            for (int vs = 0; vs < VS; ++vs) {
+                const float *src = hval + (size_t)(vs * TB * CELLS + tid) * 4;
+                hv0 += src[0]; hv1 += src[1]; hv2 += src[2];
+            }
         }
     }
     if (!VMFMA && tid < TB * CELLS) {
@@ -1015,27 +1070,44 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
         }
         vlogit = nullptr;
     } else {
-        // wide action spaces (Gomoku: 81): one thread per (board, action) walks the 32 x CELLS inputs in
-        // flatten order; weights are stored [input][AP] so that the threads of a board read them coalesced
+        // wide action spaces (Gomoku: 81): the 32 input channels of an output are cut into KS slices (whole channels, a
+        // slice walks its CELLS inputs per channel in flatten order), one thread per (slice, board, output); weights are
+        // stored [input][AP] so that the threads of a slice read them coalesced, nine loads in flight per thread.  The
+        // slices are added in order after the barrier.
+        constexpr int NOUT = TB * (A + 1);                    // per board: A policy logits + the value logit
+        constexpr int KS = NTHREADS / NOUT >= 8 ? 8 : (NTHREADS / NOUT >= 4 ? 4 : (NTHREADS / NOUT >= 2 ? 2 : 1));
+        constexpr int CS = POL_CH / KS;                       // channels per slice
+        static_assert(KS * NOUT <= WG_ROWS * 8, "the partial sums [KS][NOUT] fit the FC partial-sum area");
+        auto fslot = [&](int i) -> float & { return part[(i >> 3) * PSTR + (i & 7)]; };
 #pragma unroll 1
-        for (int t = tid; t < TB * (A + 1); t += NTHREADS) {
-            const int b = t / (A + 1), o = t % (A + 1);
+        for (int t = tid; t < KS * NOUT; t += NTHREADS) {
+            const int ks = t / NOUT, item = t % NOUT, b = item / (A + 1), o = item % (A + 1);
             float sum = 0.0f;
             if (o < A) {
 #pragma unroll 1
-                for (int c = 0; c < POL_CH; ++c)
-#pragma unroll 3
-                    for (int pos = 0; pos < CELLS; ++pos)
-                        sum = fmaf(act[(b * CELLS + pos) * STRIDE + c], P.fcp_w[((size_t)c * CELLS + pos) * AP + o], sum);
-                logits[b * AP + o] = sum + P.fcp_b[o];
-            } else {
+                for (int c = ks * CS; c < (ks + 1) * CS; ++c) {
+                    const float *ap = act + (size_t)b * CELLS * STRIDE + c;
+                    const float *wp = P.fcp_w + (size_t)c * CELLS * AP + o;
+#pragma unroll 9
+                    for (int pos = 0; pos < CELLS; ++pos) sum = fmaf(ap[pos * STRIDE], wp[(size_t)pos * AP], sum);
+                }
+            } else if (ks == 0) {
 #pragma unroll 1
                 for (int c = 0; c < VAL_CH; ++c)
-#pragma unroll 1
+#pragma unroll 3
                     for (int pos = 0; pos < CELLS; ++pos)
                         sum = fmaf(hval[(b * CELLS + pos) * 4 + c], P.fcv_w[c * CELLS + pos], sum);
-                vl[b] = sum + P.fcv_b[0];
             }
+            fslot(t) = sum;
+        }
+        __syncthreads();
+        for (int item = tid; item < NOUT; item += NTHREADS) {
+            const int b = item / (A + 1), o = item % (A + 1);
+            float sum = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) sum += fslot(ks * NOUT + item);
+            if (o < A) logits[b * AP + o] = sum + P.fcp_b[o];
+            else vl[b] = sum + P.fcv_b[0];
         }
         vlogit = vl;
     }
@@ -1073,22 +1145,40 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
                 }
             }
         }
-    } else if (tid < TB && board0 + tid < n_leaf) {
+    } else {
+        // wide action spaces: wave b takes board b, a lane the actions lane and lane + 64; maximum and denominator by
+        // butterfly reductions (every lane adds the same pairs in the same order)
         static_assert(A <= 7 || !FUSED, "FUSED rounds exist for Connect-4");
-        const int j = board0 + tid;
-        const int slot = leaf_slot[j];
-        const typename G::B bmine = board_load_strided<G::W>(mine, slot, bstride), btheirs = board_load_strided<G::W>(theirs, slot, bstride);
-        const float *lg = logits + tid * AP;
-        float mx = -INFINITY;
-#pragma unroll 1
-        for (int a = 0; a < A; ++a) if (G::legal(bmine, btheirs, a)) mx = fmaxf(mx, lg[a]);
-        float den = 0.0f;
-#pragma unroll 1
-        for (int a = 0; a < A; ++a) den += G::legal(bmine, btheirs, a) ? expf(lg[a] - mx) : 0.0f;
-#pragma unroll 1
-        for (int a = 0; a < AP; ++a)
-            out_p[(size_t)slot * AP + a] = (a < A && G::legal(bmine, btheirs, a)) ? expf(lg[a] - mx) / den : 0.0f;     // results by slot
-        out_v[slot] = tanhf(vlogit ? vlogit[tid] : lg[7]);
+        static_assert(A <= 128 && AP <= 128 && TB <= NTHREADS / 64, "one wave per board, two actions per lane");
+        const int b = tid >> 6;
+        if (b < TB && board0 + b < n_leaf) {
+            const int slot = leaf_slot[board0 + b];
+            const typename G::B bmine = board_load_strided<G::W>(mine, slot, bstride), btheirs = board_load_strided<G::W>(theirs, slot, bstride);
+            const float *lg = logits + b * AP;
+            float x[2], ex[2];
+            bool leg[2];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int a = lane + 64 * i;
+                leg[i] = a < A && G::legal(bmine, btheirs, a);
+                x[i] = a < A ? lg[a] : 0.0f;
+                if (leg[i]) mx = fmaxf(mx, x[i]);
+            }
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+            ex[0] = leg[0] ? expf(x[0] - mx) : 0.0f;
+            ex[1] = leg[1] ? expf(x[1] - mx) : 0.0f;
+            float den = ex[0] + ex[1];
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) den += __shfl_xor(den, m, 64);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int a = lane + 64 * i;
+                if (a < AP) out_p[(size_t)slot * AP + a] = leg[i] ? ex[i] / den : 0.0f;     // results by slot
+            }
+            if (lane == 0) out_v[slot] = tanhf(vlogit ? vlogit[b] : lg[7]);
+        }
     }
     STAMP(55);
     if constexpr (FUSED) {
