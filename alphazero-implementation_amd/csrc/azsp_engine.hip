@@ -108,6 +108,7 @@ struct azsp_engine {
     double *d_noise = nullptr;        // root exploration noise staging
     float *d_stage_p = nullptr, *d_stage_v = nullptr;   // host evaluator: results in list order before the scatter to slots
     size_t leaf_off = 0;              // byte offset of the leaf position inside a slot record
+    int32_t eval_off = -1;            // byte offset of the evaluator's row inside a slot record, -1 = separate arrays
     bool fused_rounds_allowed = true; // AZSP_FUSED_ROUNDS=0 at engine creation: keep the two-launch rounds (A/B, tests)
     double *d_st_wd = nullptr, *d_st_rwd = nullptr;   // float64 root statistics staging
     double *d_sqrt = nullptr, *d_ctab = nullptr, *d_expl = nullptr;   // [n_sims + 2] exploration tables
@@ -205,7 +206,7 @@ static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
             EventPair *p = ev_begin(e, EV_INFER, st);
             // leaf positions sit in the slot records; outputs are indexed by slot, so groups never share rows
             resnet_forward(e->net, game, reinterpret_cast<const u64 *>(v.slot + e->leaf_off), v.slot_bytes / 8, v.leaf_slot + v.lo, v.nl,
-                           v.n_act, v.eval_p, v.eval_v, st);
+                           v.n_act, v.eval_p, v.eval_pstride, v.eval_v, v.eval_vstride, st);
             ev_end(p, st);
             e->stats.infer_launches++;
             return 0;
@@ -492,8 +493,9 @@ static int create_impl(azsp_engine *e) {
     v.max_plies = gi.max_plies;
     v.cells = gi.cells;
     {
-        int32_t blk = 0, slot = 0, dcap = 0;
-        tree_geometry(c.game, &blk, &slot, &dcap);
+        int32_t blk = 0, slot = 0, dcap = 0, eoff = -1;
+        tree_geometry(c.game, &blk, &slot, &dcap, &eoff);
+        e->eval_off = eoff;
         v.rec_block = blk;
         v.rec_slot = (int64_t)v.E * blk;
         v.slot_bytes = slot;
@@ -511,7 +513,15 @@ static int create_impl(azsp_engine *e) {
     HIP_TRY(hipMemset(v.leaf_slot, 0, (size_t)N * sizeof(int32_t)));
     HIP_TRY(hipMemset(v.leaf_slot2, 0, (size_t)N * sizeof(int32_t)));
     HIP_TRY(hipMemset(v.n_leaf, 0, MAX_GROUPS * 4 * sizeof(int32_t)));
-    DEV_ALLOC(v.eval_p, (size_t)N * AP); DEV_ALLOC(v.eval_v, N);
+    if (e->eval_off >= 0) {           // narrow action spaces: (p[0..A), value at [7]) inside the slot record
+        v.eval_p = reinterpret_cast<float *>(v.slot + e->eval_off);
+        v.eval_v = v.eval_p + 7;
+        v.eval_pstride = v.eval_vstride = v.slot_bytes / 4;
+    } else {
+        DEV_ALLOC(v.eval_p, (size_t)N * AP); DEV_ALLOC(v.eval_v, N);
+        v.eval_pstride = AP;
+        v.eval_vstride = 1;
+    }
     DEV_ALLOC(e->d_stage_p, (size_t)N * AP); DEV_ALLOC(e->d_stage_v, N);
     e->tab_len = v.reuse ? (S + 1) * gi.max_plies + 2 : S + 2;    // largest N_parent + 1 a search can see
     DEV_ALLOC(e->d_sqrt, e->tab_len); DEV_ALLOC(e->d_ctab, e->tab_len); DEV_ALLOC(e->d_expl, e->tab_len);
@@ -650,13 +660,19 @@ int azsp_predict(azsp_engine *e, const int8_t *boards, int32_t n, float *p_out, 
         launch_compact(e->v, e->stream);
         rc = evaluate_leaves(e, e->v, e->stream);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(e->h_p8.data(), e->v.eval_p, (size_t)m * AP * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipMemcpyAsync(e->h_v.data(), e->v.eval_v, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        const bool in_slot = e->eval_off >= 0;         // rows of AP floats, one per slot record (value = element 7)
+        if (in_slot) {
+            HIP_TRY(hipMemcpy2DAsync(e->h_p8.data(), (size_t)AP * sizeof(float), e->v.eval_p, (size_t)e->v.slot_bytes,
+                                     (size_t)AP * sizeof(float), (size_t)m, hipMemcpyDeviceToHost, e->stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(e->h_p8.data(), e->v.eval_p, (size_t)m * AP * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->h_v.data(), e->v.eval_v, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        }
         rc = sync_stream(e);
         if (rc) return rc;
         for (int j = 0; j < m; ++j) {
             if (p_out) for (int a = 0; a < A; ++a) p_out[(size_t)(lo + j) * A + a] = e->h_p8[(size_t)j * AP + a];
-            if (v_out) v_out[lo + j] = e->h_v[j];
+            if (v_out) v_out[lo + j] = in_slot ? e->h_p8[(size_t)j * AP + 7] : e->h_v[j];
         }
     }
     e->v.n_act = N;

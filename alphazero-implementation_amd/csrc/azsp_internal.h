@@ -46,7 +46,12 @@ struct TreeGeo {
     static constexpr int BLOCK_BYTES = ((A + 1) * 16 + 127) & ~127;
     static constexpr int HEAD_CHUNKS = 3;                                  // SlotHead
     static constexpr int LEAF_CHUNK = HEAD_CHUNKS;                         // first chunk of the leaf position
-    static constexpr int PATH_CHUNK = HEAD_CHUNKS + G::W;                  // first chunk of the path (2 u64 per chunk: mine | theirs per word pair)
+    // narrow action spaces (A <= 7: AP = 8 floats): the evaluator writes the leaf's (p[0..A), value at [7]) INTO the slot
+    // record, right behind the leaf position -- the 32 bytes arrive with the record's first line instead of as two more
+    // dependent requests per simulation; wide ones (Gomoku: 88 floats) keep a separate row per slot
+    static constexpr bool EVAL_IN_SLOT = G::AP == 8;
+    static constexpr int EVAL_CHUNK = HEAD_CHUNKS + G::W;                  // first chunk of the evaluator's row (EVAL_IN_SLOT)
+    static constexpr int PATH_CHUNK = EVAL_CHUNK + (EVAL_IN_SLOT ? 2 : 0); // first chunk of the path
     static constexpr int D = G::MAX_PLIES + 2;                             // path capacity
     static constexpr int SLOT_BYTES = (PATH_CHUNK * 16 + D * 4 + 127) & ~127;
     static constexpr int SLOT_CHUNKS = SLOT_BYTES / 16;
@@ -86,8 +91,9 @@ struct View {
     int32_t *leaf_slot2;    // [n_slots] second leaf list (FUSED rounds read one list while filling the other)
     int32_t *nl;            // the counter this launch reads / fills: n_leaf + grp * 2 + parity
     int32_t *nl_other;      // the group's other counter (the fused kernel zeroes it for the round after)
-    float   *eval_p;        // [n_slots][AP] evaluator output, indexed by SLOT (AP = A padded to 8)
-    float   *eval_v;        // [n_slots]
+    float   *eval_p;        // evaluator output of slot g: p at eval_p + g * eval_pstride, value at eval_v + g * eval_vstride
+    float   *eval_v;        // (inside the slot records when TreeGeo<G>::EVAL_IN_SLOT, else [n_slots][AP] and [n_slots])
+    int32_t  eval_pstride, eval_vstride;      // in floats
     const double *sqrt_tab; // [tab_len] host-computed sqrt(N): bit-identical to math.sqrt
     const double *c_tab;    // [tab_len] exploration factor c(N): 1.0 unless options say otherwise
     const double *expl_tab; // [tab_len] c(N) * sqrt(N)  (== sqrt_tab bit for bit while c == 1)
@@ -128,7 +134,7 @@ struct PlyResultDev {   // mirrors azsp_ply_result; written by k_emit_scan into 
 };
 
 // launchers (azsp_tree.hip)
-void tree_geometry(int game, int32_t *block_bytes, int32_t *slot_bytes, int32_t *path_cap);
+void tree_geometry(int game, int32_t *block_bytes, int32_t *slot_bytes, int32_t *path_cap, int32_t *eval_off);   // eval_off: byte offset of the evaluator's row in a slot record, -1 = separate arrays
 void launch_root_prepare(int game, const View &v, hipStream_t s);
 void launch_select(int game, const View &v, hipStream_t s);
 void launch_compact(const View &v, hipStream_t s);
@@ -159,7 +165,8 @@ size_t resnet_blob_floats(int game, int blocks, int channels);
 // evaluates the leaf positions of the slots leaf_slot[j], j < *n_leaf (<= max_leaves), into out_p[slot][AP] / out_v[slot];
 // the position of slot g: mine = leaf0 + g * board_stride (W words), theirs = the W words after it
 void resnet_forward(ResNetDev *, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot,
-                    const int32_t *n_leaf, int max_leaves, float *out_p, float *out_v, hipStream_t s);
+                    const int32_t *n_leaf, int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s);
+// (results of slot g: p at out_p + g * p_stride, value at out_v + g * v_stride -- strides in floats)
 // FUSED rounds (large-batch Connect-4 kernels of the fp32 network): one launch evaluates the listed leaves AND carries
 // those games on to their next leaf (azsp_tree_dev.h advance_game)
 bool resnet_has_fused(const ResNetDev *, int game, int max_leaves);
@@ -177,6 +184,6 @@ ResNet16Dev *resnet16_create(int game, int blocks, int channels);
 void resnet16_destroy(ResNet16Dev *);
 int resnet16_load(ResNet16Dev *, const float *blob, size_t n_floats, hipStream_t s);
 void resnet16_forward(ResNet16Dev *, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
-                      int max_leaves, float *out_p, float *out_v, hipStream_t s);
+                      int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s);
 
 }  // namespace azsp

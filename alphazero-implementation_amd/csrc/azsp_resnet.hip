@@ -349,11 +349,11 @@ static void (*fused_launcher(const ResNetDev *n, int game, int max_leaves))(cons
 bool resnet_has_fused(const ResNetDev *n, int game, int max_leaves) { return n && fused_launcher(n, game, max_leaves) != nullptr; }
 
 static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
-                         int max_leaves, float *out_p, float *out_v, hipStream_t s, const FusedArgs *fused);
+                         int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, const FusedArgs *fused);
 
 void resnet_forward(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
-                    int max_leaves, float *out_p, float *out_v, hipStream_t s) {
-    forward_impl(n, game, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s, nullptr);
+                    int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s) {
+    forward_impl(n, game, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s, nullptr);
 }
 
 // One FUSED round of a slot group: evaluates the leaves listed in leaf_slot[0 .. *n_leaf) and carries those games on
@@ -366,12 +366,12 @@ void resnet_forward_fused(ResNetDev *n, int game, const View &view, const u64 *l
     f.next_list = next_list;
     f.next_count = next_count;
     f.zero_count = zero_count;
-    forward_impl(n, game, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, nullptr, nullptr, s, &f);
+    forward_impl(n, game, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, nullptr, 0, nullptr, 0, s, &f);
 }
 
 static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
-                         int max_leaves, float *out_p, float *out_v, hipStream_t s, const FusedArgs *fused) {
-    if (n->f16) { resnet16_forward(n->f16, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s); return; }
+                         int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, const FusedArgs *fused) {
+    if (n->f16) { resnet16_forward(n->f16, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s); return; }
     const Variant *v = pick_variant(n, game, max_leaves);
     if (!v) return;                        // resnet_create refused every geometry without a variant
     FwdArgs a;
@@ -391,7 +391,7 @@ static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_str
     P.perm = n->d_perm ? n->d_perm + v->perm_offset : nullptr;
     P.conv_w4 = n->has_w4 ? d + n->o_conv_w4 : nullptr;
     a.mine = leaf0; a.theirs = leaf0 + n->g_words; a.bstride = board_stride; a.leaf_slot = leaf_slot; a.n_leaf = n_leaf; a.max_leaves = max_leaves;
-    a.out_p = out_p; a.out_v = out_v; a.s = s;
+    a.out_p = out_p; a.out_v = out_v; a.p_stride = p_stride; a.v_stride = v_stride; a.s = s;
     if (fused) fused_launcher(n, game, max_leaves)(a);
     else v->launch(a);
 }

@@ -282,7 +282,7 @@ template <class G, int CT, int WR, int ABL = 0>
 __global__ __launch_bounds__(64 * WR * CT, 2)
 void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs, int bstride,
                           const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
-                          float *__restrict__ out_p, float *__restrict__ out_v) {
+                          float *__restrict__ out_p, float *__restrict__ out_v, int p_stride, int v_stride) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
     constexpr int MT = 8 / WR, WAVES = WR * CT, NTHREADS = 64 * WAVES;
     constexpr int TB = F16_ROWS / CELLS;
@@ -518,8 +518,8 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
 #pragma unroll
         for (int a = 0; a < A; ++a) { ex[a] = ((legal >> a) & 1u) ? expf(logits[tid * 8 + a] - mx) : 0.0f; den += ex[a]; }
 #pragma unroll
-        for (int a = 0; a < Connect4::AP; ++a) out_p[(size_t)slot * Connect4::AP + a] = a < A ? ex[a < A ? a : 0] / den : 0.0f;
-        out_v[slot] = tanhf(logits[tid * 8 + 7]);
+        for (int a = 0; a < Connect4::AP; ++a) out_p[(size_t)slot * p_stride + a] = a < A ? ex[a < A ? a : 0] / den : 0.0f;
+        out_v[(size_t)slot * v_stride] = tanhf(logits[tid * 8 + 7]);
     }
     STAMP16(55);
 }
@@ -702,7 +702,7 @@ int resnet16_load(ResNet16Dev *n, const float *blob, size_t n_floats, hipStream_
 
 template <int CT, int WR, int ABL = 0>
 static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, int bstride, const int32_t *leaf_slot, const int32_t *n_leaf,
-                     int max_leaves, float *out_p, float *out_v, hipStream_t s) {
+                     int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s) {
     using G = Connect4;
     constexpr int WAVES = WR * CT, RS = 32 * CT + 8, TB = F16_ROWS / G::CELLS;
     constexpr size_t planes = (size_t)2 * (F16_ROWS + 1) * RS * 2;
@@ -721,11 +721,11 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, i
     const int grid = (max_leaves + TB - 1) / TB;
     Net16Params Q = P;
     Q.perm = P.perm + (size_t)(WR == 1 ? 0 : WR == 2 ? 1 : WR == 4 ? 2 : 3) * F16_ROWS;      // row order of this wave grid
-    hipLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR, ABL>), dim3(grid), dim3(64 * WAVES), lds, s, Q, mine, theirs, bstride, leaf_slot, n_leaf, out_p, out_v);
+    hipLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR, ABL>), dim3(grid), dim3(64 * WAVES), lds, s, Q, mine, theirs, bstride, leaf_slot, n_leaf, out_p, out_v, p_stride, v_stride);
 }
 
 void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32_t *leaf_slot, const int32_t *n_leaf,
-                      int max_leaves, float *out_p, float *out_v, hipStream_t s) {
+                      int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s) {
     const u64 *mine = leaf0, *theirs = leaf0 + Connect4::W;
     Net16Params P;
     unsigned char *d = n->d_blob;
@@ -741,7 +741,7 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
     P.dbg = nullptr;
     // wave grid WR x CT over the 256-row x C tile (tuning knob AZSP_F16_WR; results do not depend on it)
     static const int wr_env = [] { const char *e = getenv("AZSP_F16_WR"); return e ? atoi(e) : 0; }();
-#define L16(CTV, WRV) launch16<CTV, WRV>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s)
+#define L16(CTV, WRV) launch16<CTV, WRV>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s)
     switch (n->CT) {
         case 1: if (wr_env == 8 || (!wr_env && max_leaves <= 768)) L16(1, 8); else L16(1, 4); break;
         case 2: {
@@ -755,7 +755,7 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
                     (void)hipMemsetAsync(dd, 0, cnt * 8, s);
                     Net16Params Q = P;
                     Q.dbg = dd;
-                    launch16<2, 2, 8>(Q, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+                    launch16<2, 2, 8>(Q, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s);
                     (void)hipStreamSynchronize(s);
                     std::vector<unsigned long long> h(cnt);
                     (void)hipMemcpy(h.data(), dd, cnt * 8, hipMemcpyDeviceToHost);
@@ -785,10 +785,10 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
             }
             static const int abl = [] { const char *e = getenv("AZSP_F16_ABLATE"); return e ? atoi(e) : 0; }();
             if (abl) {   // timing-only diagnostic builds (wrong results): 1 = no weight streaming, 2 = no LDS fragment traffic, 4 = no activation stores
-                if (abl == 1) launch16<2, 2, 1>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
-                else if (abl == 2) launch16<2, 2, 2>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
-                else if (abl == 3) launch16<2, 2, 3>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
-                else launch16<2, 2, 4>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, s);
+                if (abl == 1) launch16<2, 2, 1>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s);
+                else if (abl == 2) launch16<2, 2, 2>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s);
+                else if (abl == 3) launch16<2, 2, 3>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s);
+                else launch16<2, 2, 4>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s);
                 break;
             }
             if (wr_env == 4 || (!wr_env && max_leaves <= 768)) L16(2, 4); else L16(2, 2);   // small batch: more waves per board

@@ -526,7 +526,7 @@ __device__ __forceinline__ void conv_tile16(f32x4m (&acc)[5][2], float (&vacc)[2
 template <class G, int NT, int MT, int PF, int CW = 1, int RW = 4, bool TR = false, bool FUSED = false>
 __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 && NT <= 2 ? 3 : (RW * CW == 16 ? 1 : (RW * CW > 8 ? RW * CW / 4 : (RW * CW == 8 && RW * MT == 8 ? 1 : 2))))) void k_resnet_forward(NetParams P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs, int bstride,
                                                          const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
-                                                         float *__restrict__ out_p, float *__restrict__ out_v,
+                                                         float *__restrict__ out_p, float *__restrict__ out_v, int p_stride, int v_stride,
                                                          typename std::conditional<FUSED, FusedArgs, int>::type F) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
     constexpr int WG_ROWS = RW * 32 * MT;          // RW row groups x MT row tiles of 32 (x CW column groups of waves)
@@ -1140,8 +1140,8 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
                     logits[b * AP + a] = pr;
                     if (a == 7) vl[b] = val;
                 } else {
-                    out_p[(size_t)slot * AP + a] = pr;           // results by slot
-                    if (a == 7) out_v[slot] = val;
+                    out_p[(size_t)slot * p_stride + a] = pr;           // results by slot
+                    if (a == 7) out_v[(size_t)slot * v_stride] = val;
                 }
             }
         }
@@ -1175,9 +1175,9 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int a = lane + 64 * i;
-                if (a < AP) out_p[(size_t)slot * AP + a] = leg[i] ? ex[i] / den : 0.0f;     // results by slot
+                if (a < AP) out_p[(size_t)slot * p_stride + a] = leg[i] ? ex[i] / den : 0.0f;     // results by slot
             }
-            if (lane == 0) out_v[slot] = tanhf(vlogit ? vlogit[b] : lg[7]);
+            if (lane == 0) out_v[(size_t)slot * v_stride] = tanhf(vlogit ? vlogit[b] : lg[7]);
         }
     }
     STAMP(55);
@@ -1218,7 +1218,8 @@ struct FwdArgs {
     int bstride;
     const int32_t *leaf_slot, *n_leaf;      // leaf list of the group (slot ids) and its length (device)
     int max_leaves;
-    float *out_p, *out_v;
+    float *out_p, *out_v;                   // results of slot g at out_p + g * p_stride, out_v + g * v_stride (floats)
+    int p_stride, v_stride;
     hipStream_t s;
     const FusedArgs *fused;                 // FUSED variants only, else nullptr
 };
@@ -1270,16 +1271,16 @@ static void launch_forward(const FwdArgs &a) {
         if (resnet_trace_wanted(&print)) {
             trace_forward(a.P, grid, [&](const NetParams &Q) {
                 hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW, true>), dim3(grid), dim3(64 * RW * CW), lds, a.s, Q,
-                                   a.mine, a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, 0); }, a.s, print);
+                                   a.mine, a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, a.p_stride, a.v_stride, 0); }, a.s, print);
             return;
         }
     }
     if constexpr (FUSED) {
         hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW, false, true>), dim3(grid), dim3(64 * RW * CW), lds, a.s, a.P, a.mine,
-                           a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, *a.fused);
+                           a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, a.p_stride, a.v_stride, *a.fused);
     } else {
         hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW>), dim3(grid), dim3(64 * RW * CW), lds, a.s, a.P, a.mine, a.theirs,
-                           a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, 0);
+                           a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, a.p_stride, a.v_stride, 0);
     }
 }
 

@@ -120,9 +120,9 @@ __device__ __forceinline__ float eval_rows(const View &v, int g, int lane, bool 
 #pragma unroll
     for (int k = 0; k < G::APL; ++k) {
         const int a = lane + k * G::LPG;
-        p32[k] = (live && a < G::A) ? v.eval_p[(size_t)g * G::AP + a] : 0.0f;
+        p32[k] = (live && a < G::A) ? v.eval_p[(size_t)g * v.eval_pstride + a] : 0.0f;
     }
-    return live ? v.eval_v[g] : 0.0f;
+    return live ? v.eval_v[(size_t)g * v.eval_vstride] : 0.0f;
 }
 
 template <class G, int R>
@@ -178,9 +178,10 @@ __global__ void k_eval_hash(View v, uint64_t salt) {
     const int g = v.leaf_slot[v.lo + j];
     typename G::B m, t;
     leaf_boards<G>(v, g, m, t);
-    float *p = v.eval_p + (size_t)g * G::AP;
-    v.eval_v[g] = hash_eval<G>(m, t, salt, p);
+    float *p = v.eval_p + (size_t)g * v.eval_pstride;
+    const float val = hash_eval<G>(m, t, salt, p);
     for (int a = G::A; a < G::AP; ++a) p[a] = 0.0f;
+    v.eval_v[(size_t)g * v.eval_vstride] = val;           // (last: inside a slot record the value is the row's element 7)
 }
 
 // host evaluator: results arrive in list order; the tree kernels read them by slot
@@ -190,8 +191,8 @@ __global__ void k_scatter_eval(View v, const float *p_compact, const float *v_co
     if (i >= v.nl[0] * G::AP) return;
     const int j = i / G::AP, a = i % G::AP;
     const int g = v.leaf_slot[v.lo + j];
-    v.eval_p[(size_t)g * G::AP + a] = p_compact[i];
-    if (a == 0) v.eval_v[g] = v_compact[j];
+    if (a < G::A) v.eval_p[(size_t)g * v.eval_pstride + a] = p_compact[i];        // (the padding is never read)
+    if (a == 0) v.eval_v[(size_t)g * v.eval_vstride] = v_compact[j];
 }
 
 template <class G, int R>
@@ -577,8 +578,9 @@ __global__ void k_export_dataset(View v, long long first, long long n, float *pl
 // launchers
 // ------------------------------------------------------------------------------------------------
 // record sizes of the game's tree layout, for the engine's allocations
-void tree_geometry(int game, int32_t *block_bytes, int32_t *slot_bytes, int32_t *path_cap) {
-    GAME_SWITCH(game, { *block_bytes = TreeGeo<G>::BLOCK_BYTES; *slot_bytes = TreeGeo<G>::SLOT_BYTES; *path_cap = TreeGeo<G>::D; });
+void tree_geometry(int game, int32_t *block_bytes, int32_t *slot_bytes, int32_t *path_cap, int32_t *eval_off) {
+    GAME_SWITCH(game, { *block_bytes = TreeGeo<G>::BLOCK_BYTES; *slot_bytes = TreeGeo<G>::SLOT_BYTES; *path_cap = TreeGeo<G>::D;
+                        *eval_off = TreeGeo<G>::EVAL_IN_SLOT ? TreeGeo<G>::EVAL_CHUNK * 16 : -1; });
 }
 void launch_root_prepare(int game, const View &v, hipStream_t s) {
     RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_root_prepare<G, R>), dim3((v.n_act + 255) / 256), dim3(256), 0, s, v));

@@ -27,6 +27,22 @@ __global__ void k_rate(int n, unsigned long long *out, float *sink) {
     if (threadIdx.x == 0) out[0] = t1 - t0;
     if (s == 1234.5f) sink[0] = s;
 }
+// dependent chains: NACC accumulators used round-robin (the Gomoku tower: the MFMA two back wrote this one's C operand)
+template <int NACC>
+__global__ void k_dep(int n, unsigned long long *out, float *sink) {
+    f32x4 a[NACC];
+    for (int i = 0; i < NACC; ++i) a[i] = (f32x4){0, 0, 0, 0};
+    const float x = threadIdx.x * 1e-3f, y = 1.0f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < n; i += 40)
+#pragma unroll
+        for (int k = 0; k < 40; ++k) a[k % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a[k % NACC], 0, 0, 0);
+    float s = 0;
+    for (int i = 0; i < NACC; ++i) s += a[i][0] + a[i][1] + a[i][2] + a[i][3];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) out[0] = t1 - t0;
+    if (s == 1234.5f) sink[0] = s;
+}
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ void k_rate32(int n, unsigned long long *out, float *sink) {
     f32x16 a[4];
@@ -61,6 +77,9 @@ int main() {
     k_rate<<<1, 64>>>(N, dt, dD); k_rate<<<1, 64>>>(N, dt, dD);
     hipMemcpy(&ht, dt, 8, hipMemcpyDeviceToHost);
     printf("rate: %.2f ticks per v_mfma_f32_16x16x4_f32 (the 64-cycle 32x32x2 form measures 72 of these ticks)\n", (double)ht / N);
+#define DEP(NA) k_dep<NA><<<1, 64>>>(N, dt, dD); k_dep<NA><<<1, 64>>>(N, dt, dD); hipMemcpy(&ht, dt, 8, hipMemcpyDeviceToHost); \
+    printf("dependent chains, %d accumulators round-robin: %.2f ticks per MFMA\n", NA, (double)ht / N);
+    DEP(1) DEP(2) DEP(4) DEP(5)
     k_rate32<<<1, 64>>>(N, dt, dD); k_rate32<<<1, 64>>>(N, dt, dD);
     hipMemcpy(&ht, dt, 8, hipMemcpyDeviceToHost);
     printf("rate: %.2f ticks per v_mfma_f32_32x32x2_f32 (20 per loop iteration, 4 accumulators)\n", (double)ht / N);
