@@ -109,7 +109,7 @@ struct azsp_engine {
     float *d_stage_p = nullptr, *d_stage_v = nullptr;   // host evaluator: results in list order before the scatter to slots
     size_t leaf_off = 0;              // byte offset of the leaf position inside a slot record
     int32_t eval_off = -1;            // byte offset of the evaluator's row inside a slot record, -1 = separate arrays
-    bool fused_rounds_allowed = true; // AZSP_FUSED_ROUNDS=0 at engine creation: keep the two-launch rounds (A/B, tests)
+    int fused_rounds_mode = 2;        // AZSP_FUSED_ROUNDS at engine creation: 0 never, 1 wherever a fused kernel exists, unset = 2: up to 32 games only
     double *d_st_wd = nullptr, *d_st_rwd = nullptr;   // float64 root statistics staging
     double *d_sqrt = nullptr, *d_ctab = nullptr, *d_expl = nullptr;   // [n_sims + 2] exploration tables
     double c_init = 1.0, c_base = 0.0;
@@ -263,13 +263,15 @@ static int search(azsp_engine *e, int n_act) {
     // games' next leaves itself (a game whose descent ends on a terminal leaf backs it up and descends again in the same
     // launch), so there is no tree launch, no gap and no evaluator output in HBM.  Round r reads list r & 1 / counter
     // r % 3, fills list (r + 1) & 1 / counter (r + 1) % 3 and clears counter (r + 2) % 3 (the one the previous launch
-    // read).  Bit-exact (tested), but NOT the default: measured 2101 against 2209 episodes/s at the headline (128
-    // channels: 290 against 294) -- the tree step is a chain of dependent loads during which the workgroup's other three
-    // waves idle while it keeps one of the CU's two workgroup slots, so both residents are outside their towers more
-    // often and the matrix pipe idles more than the removed launches had cost.
-    bool fused_rounds = e->fused_rounds_allowed && e->evaluator == AZSP_EVAL_RESNET && e->net && e->net_loaded &&
+    // read).  Bit-exact (tested).  The default for a FEW games (up to 32, one-board kernels): there a round is launch
+    // latency and one launch instead of two is 3-5 % less of it.  NOT the default otherwise: measured 2101 against 2209
+    // episodes/s at the headline (128 channels: 290 against 294) -- the tree step is a chain of dependent loads during
+    // which the workgroup's other three waves idle while it keeps one of the CU's two workgroup slots, so both residents are
+    // outside their towers more often and the matrix pipe idles more than the removed launches had cost.
+    bool fused_rounds = e->fused_rounds_mode != 0 && e->evaluator == AZSP_EVAL_RESNET && e->net && e->net_loaded &&
                         e->cfg.search_rules == AZSP_RULES_SIMPLE && !e->v.reuse && e->v.root_noise == nullptr;
-    for (int k = 0; k < G && fused_rounds; ++k) fused_rounds = resnet_has_fused(e->net, game, gv[k].n_act);
+    for (int k = 0; k < G && fused_rounds; ++k)
+        fused_rounds = resnet_has_fused(e->net, game, gv[k].n_act, e->fused_rounds_mode == 2, e->v.tab_lds);
     for (int k = 0; k < G; ++k) {
         hipStream_t st = e->gstream[k];
         launch_root_prepare(game, gv[k], st);
@@ -464,7 +466,7 @@ static int create_impl(azsp_engine *e) {
     const azsp_config &c = e->cfg;
     const GameInfo &gi = e->gi;
     ON_DEVICE(c.device);
-    { const char *x = getenv("AZSP_FUSED_ROUNDS"); e->fused_rounds_allowed = x && atoi(x) != 0; }     // opt-in: measured slower (below)
+    { const char *x = getenv("AZSP_FUSED_ROUNDS"); e->fused_rounds_mode = x ? (atoi(x) != 0 ? 1 : 0) : 2; }
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->gstream[0] = e->stream;
     e->n_groups = c.n_groups > 0 ? (c.n_groups > MAX_GROUPS ? MAX_GROUPS : c.n_groups) : (c.n_slots >= 3072 ? 3 : (c.n_slots >= 1024 ? 2 : 1));

@@ -169,7 +169,7 @@ void resnet_forward(ResNetDev *, int game, const u64 *leaf0, int board_stride, c
 // (results of slot g: p at out_p + g * p_stride, value at out_v + g * v_stride -- strides in floats)
 // FUSED rounds (large-batch Connect-4 kernels of the fp32 network): one launch evaluates the listed leaves AND carries
 // those games on to their next leaf (azsp_tree_dev.h advance_game)
-bool resnet_has_fused(const ResNetDev *, int game, int max_leaves);
+bool resnet_has_fused(const ResNetDev *, int game, int max_leaves, bool small_only, int tab_lds);
 void resnet_forward_fused(ResNetDev *, int game, const View &view, const u64 *leaf0, int board_stride, const int32_t *leaf_slot,
                           const int32_t *n_leaf, int32_t *next_list, int32_t *next_count, int32_t *zero_count, int max_leaves,
                           hipStream_t s);

@@ -338,15 +338,30 @@ int resnet_forced_variant(int game, int nt) {
     return -1;
 }
 
-// FUSED rounds exist for the large-batch Connect-4 kernels of the exact-fp32 network (64 / 128 channels)
-static void (*fused_launcher(const ResNetDev *n, int game, int max_leaves))(const FwdArgs &) {
+// FUSED rounds exist for the Connect-4 kernels of the exact-fp32 network at 64 / 128 channels: the one-board workgroups
+// of small batches (small = true) and the six-board ones of large batches
+static void (*fused_launcher(const ResNetDev *n, int game, int max_leaves, bool *small))(const FwdArgs &) {
+    if (small) *small = false;
     if (n->f16 || game != 0 || n->forced_variant >= 0) return nullptr;
     const Variant *v = pick_variant(n, game, max_leaves);
     if (v && v->launch == fwd_c4_64_big) return fwd_c4_64_big_fused;
     if (v && v->launch == fwd_c4_128_big) return fwd_c4_128_big_fused;
+    if (small) *small = true;
+    if (v && v->launch == fwd_c4_64_one) return fwd_c4_64_one_fused;
+    if (v && v->launch == fwd_c4_128_one) return fwd_c4_128_one_fused;
     return nullptr;
 }
-bool resnet_has_fused(const ResNetDev *n, int game, int max_leaves) { return n && fused_launcher(n, game, max_leaves) != nullptr; }
+// small_only: the caller wants FUSED rounds only where they are the faster form (launch-latency-bound small batches);
+// tab_lds: exploration-table entries the tree step stages in LDS over the one-board kernel's dead activation rows
+bool resnet_has_fused(const ResNetDev *n, int game, int max_leaves, bool small_only, int tab_lds) {
+    if (!n) return false;
+    bool small = false;
+    if (!fused_launcher(n, game, max_leaves, &small)) return false;
+    if (small && tab_lds > 1024) return false;              // 2 * 1024 + 480 floats of tree scratch fit 65 x 68 activation floats
+    // measured (one MI355X, 64 channels, 100 simulations): 106.6 -> 101.0 us per round with one game, 118.3 -> 114.2 with 8,
+    // 117.9 -> 121.2 with 100 (the tree tail then delays other workgroups' launch slots): the default only for a few games
+    return small_only ? small && max_leaves <= 32 : true;
+}
 
 static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
                          int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, const FusedArgs *fused);
@@ -392,7 +407,7 @@ static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_str
     P.conv_w4 = n->has_w4 ? d + n->o_conv_w4 : nullptr;
     a.mine = leaf0; a.theirs = leaf0 + n->g_words; a.bstride = board_stride; a.leaf_slot = leaf_slot; a.n_leaf = n_leaf; a.max_leaves = max_leaves;
     a.out_p = out_p; a.out_v = out_v; a.p_stride = p_stride; a.v_stride = v_stride; a.s = s;
-    if (fused) fused_launcher(n, game, max_leaves)(a);
+    if (fused) fused_launcher(n, game, max_leaves, nullptr)(a);
     else v->launch(a);
 }
 

@@ -4,4 +4,7 @@
 namespace azsp {
 void fwd_c4_64_big_fused(const FwdArgs &a) { launch_forward<Connect4, 2, 4, 0, 2, 2, false, true>(a); }
 void fwd_c4_128_big_fused(const FwdArgs &a) { launch_forward<Connect4, 4, 4, 0, 4, 2, false, true>(a); }
+// the one-board workgroups of small batches: there a round is launch latency, and one launch per round is the default
+void fwd_c4_64_one_fused(const FwdArgs &a) { launch_forward<Connect4, 2, 1, 0, 2, 2, false, true>(a); }
+void fwd_c4_128_one_fused(const FwdArgs &a) { launch_forward<Connect4, 4, 1, 0, 4, 2, false, true>(a); }
 }  // namespace azsp

@@ -604,6 +604,45 @@ def test_fused_rounds_bit_exact_vs_oracle_and_vs_two_launch_rounds(azsp, monkeyp
     assert (sa["evals"], sa["terminal_leaves"], sa["path_nodes"]) == (sb["evals"], sb["terminal_leaves"], sb["path_nodes"])
 
 
+def test_small_batches_run_fused_rounds_by_default(azsp, monkeypatch):
+    """A few games (up to 32: one-board inference kernels) run ONE launch per simulation round unless AZSP_FUSED_ROUNDS=0:
+    a round there is launch latency.  Same episodes, RNG position and evaluation accounting as the two-launch rounds, and
+    bit-exact against the C oracle fed by the device network; large batches keep two launches per round by default."""
+    import torch
+    from azsp.weights import resnet_blob
+    monkeypatch.delenv("AZSP_FUSED_ROUNDS", raising=False)
+    torch.manual_seed(5)
+    net = azsp.ResNet((6, 7), 7, 2, 64).eval()
+    blob, blocks, ch = resnet_blob(net)
+    n, sims, seed = 12, 30, 21
+    with _engine(azsp, "connect4", n, 1, res_blocks=blocks, channels=ch) as pe:
+        pe.load_resnet(blob)
+        cb = co.make_predict_cb(lambda bs: pe.predict(np.stack(bs)), (6, 7), 7)
+        ref = co.generate("connect4", sims, n, seed=seed, predict_cb=cb, trace=False)
+
+    def run(env):
+        if env is None:
+            monkeypatch.delenv("AZSP_FUSED_ROUNDS", raising=False)
+        else:
+            monkeypatch.setenv("AZSP_FUSED_ROUNDS", env)
+        np.random.seed(seed)
+        g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+        out = list(g.generate_episodes(net))
+        return out, g.last_stats, float(np.random.random_sample())
+    a, sa, ra = run(None)
+    b, sb, rb = run("0")
+    assert sa["select_launches"] == 0 and sa["infer_launches"] == sa["plies"] * (sims + 1)      # one launch per round
+    assert sb["select_launches"] > 0
+    assert ra == rb == ref["next_uniform"] and a == b
+    _assert_equals_c_oracle(a, ref, n)
+    assert (sa["evals"], sa["terminal_leaves"], sa["path_nodes"]) == (sb["evals"], sb["terminal_leaves"], sb["path_nodes"])
+    assert sa["evals"] == ref["stats"][0] and sa["terminal_leaves"] == ref["stats"][1]
+    np.random.seed(3)                                        # a large batch: two launches per round by default
+    g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, 5, 3000, 1, 1))
+    list(g.generate_episodes(net))
+    assert g.last_stats["select_launches"] > 0
+
+
 def test_error_paths(azsp):
     from azsp._lib import AzspError
     with pytest.raises(AzspError):
