@@ -109,6 +109,12 @@ struct azsp_engine {
     float *d_stage_p = nullptr, *d_stage_v = nullptr;   // host evaluator: results in list order before the scatter to slots
     size_t leaf_off = 0;              // byte offset of the leaf position inside a slot record
     int32_t eval_off = -1;            // byte offset of the evaluator's row inside a slot record, -1 = separate arrays
+    // AZSP_GRAPH=1 at engine creation: the launches of one ply's search (a fixed sequence for a given number of active
+    // slots and engine state) are captured once into a HIP graph and replayed
+    struct SearchGraph { int n_act; unsigned epoch; hipGraphExec_t exec; azsp_stats delta; uint64_t rounds; };
+    std::vector<SearchGraph> graphs;
+    bool graph_mode = false, graph_warm = false;
+    unsigned epoch = 0;               // bumped by whatever changes what a search enqueues (evaluator, weights, options)
     int fused_rounds_mode = 2;        // AZSP_FUSED_ROUNDS at engine creation: 0 never, 1 wherever a fused kernel exists, unset = 2: up to 32 games only
     double *d_st_wd = nullptr, *d_st_rwd = nullptr;   // float64 root statistics staging
     double *d_sqrt = nullptr, *d_ctab = nullptr, *d_expl = nullptr;   // [n_sims + 2] exploration tables
@@ -241,7 +247,7 @@ static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
 // chain select -> compact -> evaluate -> expand is enqueued on its own HIP stream: the tail of one
 // group's inference launch overlaps the next group's, and the latency-bound tree kernels of one
 // group hide behind the other's MFMA work.  Results do not depend on the grouping.
-static int search(azsp_engine *e, int n_act) {
+static int search_enqueue(azsp_engine *e, int n_act) {
     const int game = e->cfg.game;
     int G = e->n_groups;
     if (e->evaluator == AZSP_EVAL_HOST || n_act < 64 * G) G = 1;
@@ -370,6 +376,50 @@ static int search(azsp_engine *e, int n_act) {
     return 0;
 }
 
+// One ply's search.  With AZSP_GRAPH=1 the second search of a given shape is captured from the engine's streams (the
+// group streams fork from and join the main stream through events, which capture follows) and every later one is ONE
+// graph launch; the timing flag (events read back later) and the host-callback evaluator (synchronises) keep streams.
+static int search(azsp_engine *e, int n_act) {
+    if (!e->graph_mode || (e->cfg.flags & AZSP_FLAG_TIMING) || e->evaluator == AZSP_EVAL_HOST || e->v.root_noise != nullptr)
+        return search_enqueue(e, n_act);
+    for (auto &g : e->graphs)
+        if (g.n_act == n_act && g.epoch == e->epoch) {
+            HIP_TRY(hipGraphLaunch(g.exec, e->stream));
+            e->stats.plies += g.delta.plies;
+            e->stats.select_launches += g.delta.select_launches;
+            e->stats.expand_launches += g.delta.expand_launches;
+            e->stats.infer_launches += g.delta.infer_launches;
+            e->rounds_host += g.rounds;
+            e->v.lo = 0; e->v.grp = 0; e->v.n_act = n_act;
+            e->searched = true;
+            return 0;
+        }
+    if (!e->graph_warm) { e->graph_warm = true; return search_enqueue(e, n_act); }      // first: let every kernel set itself up
+    const azsp_stats before = e->stats;
+    const uint64_t rounds_before = e->rounds_host;
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = search_enqueue(e, n_act);
+    const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess || !graph) return fail(AZSP_ERR_HIP, "graph capture of a search failed: %s", hipGetErrorString(ce));
+    azsp_engine::SearchGraph g{};
+    g.n_act = n_act;
+    g.epoch = e->epoch;
+    const hipError_t ie = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) return fail(AZSP_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+    g.delta.plies = e->stats.plies - before.plies;
+    g.delta.select_launches = e->stats.select_launches - before.select_launches;
+    g.delta.expand_launches = e->stats.expand_launches - before.expand_launches;
+    g.delta.infer_launches = e->stats.infer_launches - before.infer_launches;
+    g.rounds = e->rounds_host - rounds_before;
+    if (e->graphs.size() >= 4) { (void)hipGraphExecDestroy(e->graphs.front().exec); e->graphs.erase(e->graphs.begin()); }
+    e->graphs.push_back(g);
+    HIP_TRY(hipGraphLaunch(g.exec, e->stream));          // the capture enqueued nothing: this is the search itself
+    return 0;
+}
+
 template <class G>
 static void rules_eval(const int8_t *cells, int32_t action, int8_t *next_cells, int32_t *legal_mask, int32_t *terminal) {
     typename G::B m, t, nm, nt;
@@ -437,6 +487,7 @@ void azsp_destroy(azsp_engine *e) {
         if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
         if (e->gstream[k]) (void)hipStreamDestroy(e->gstream[k]);
     }
+    for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     if (e->net) resnet_destroy(e->net);
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->h_res) (void)hipHostFree(e->h_res);
@@ -467,6 +518,7 @@ static int create_impl(azsp_engine *e) {
     const GameInfo &gi = e->gi;
     ON_DEVICE(c.device);
     { const char *x = getenv("AZSP_FUSED_ROUNDS"); e->fused_rounds_mode = x ? (atoi(x) != 0 ? 1 : 0) : 2; }
+    { const char *x = getenv("AZSP_GRAPH"); e->graph_mode = x && atoi(x) != 0; }
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->gstream[0] = e->stream;
     e->n_groups = c.n_groups > 0 ? (c.n_groups > MAX_GROUPS ? MAX_GROUPS : c.n_groups) : (c.n_slots >= 3072 ? 3 : (c.n_slots >= 1024 ? 2 : 1));
@@ -613,6 +665,7 @@ int azsp_set_evaluator(azsp_engine *e, int32_t kind, azsp_predict_fn fn, void *u
     if (kind < 0 || kind > AZSP_EVAL_HOST) return fail(AZSP_ERR_ARG, "unknown evaluator kind %d", kind);
     e->evaluator = kind;
     e->cb = fn;
+    e->epoch++;
     e->cb_user = user;
     return 0;
 }
@@ -627,6 +680,7 @@ int azsp_load_resnet(azsp_engine *e, const float *blob, size_t n_floats) {
     if (resnet_load(e->net, blob, n_floats, e->stream)) return fail(AZSP_ERR_HIP, "weight upload failed");
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->net_loaded = true;
+    e->epoch++;
     return 0;
 }
 
@@ -747,6 +801,7 @@ int azsp_set_search_options(azsp_engine *e, const azsp_search_options *o) {
         return fail(AZSP_ERR_ARG, "c_init / c_base must be numbers, c_base >= 0");
     ON_DEVICE(e->cfg.device);
     HIP_TRY(hipStreamSynchronize(e->stream));      // no search may be reading the tables
+    e->epoch++;
     e->v.sampling_plies = o->sampling_plies;
     e->v.noise_eps = o->noise_eps;
     e->v.noise_keep = 1.0 - o->noise_eps;

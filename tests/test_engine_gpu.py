@@ -643,6 +643,33 @@ def test_small_batches_run_fused_rounds_by_default(azsp, monkeypatch):
     assert g.last_stats["select_launches"] > 0
 
 
+def test_graph_replay_of_a_search_changes_nothing(azsp, monkeypatch):
+    """AZSP_GRAPH=1: from its second search on, an engine replays one ply's launches as a captured HIP graph (measured: no
+    faster than the streams -- kept as a tested option).  Same episodes, RNG position and accounting as without it."""
+    import torch
+    torch.manual_seed(2)
+    net = azsp.ResNet((6, 7), 7, 2, 64).eval()
+
+    def run(env, n, sims):
+        monkeypatch.setenv("AZSP_GRAPH", env)
+        np.random.seed(17)
+        g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+        out = list(g.generate_episodes(net))
+        return out, g.last_stats, float(np.random.random_sample())
+    for n, sims in ((6, 20), (700, 12)):                       # fused one-board rounds; three groups on three streams
+        a, sa, ra = run("1", n, sims)
+        b, sb, rb = run("0", n, sims)
+        assert a == b and ra == rb
+        for k in ("plies", "evals", "terminal_leaves", "path_nodes", "infer_launches", "select_launches", "expand_launches"):
+            assert sa[k] == sb[k], k
+    monkeypatch.setenv("AZSP_GRAPH", "1")
+    ref = co.generate("connect4", 15, 40, salt=77, seed=5, trace=False)
+    np.random.seed(5)
+    g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, 15, 40, 1, 1))
+    eps = list(g.generate_episodes(HashStub("connect4", 77)))
+    _assert_equals_c_oracle(eps, ref, 40)
+
+
 def test_error_paths(azsp):
     from azsp._lib import AzspError
     with pytest.raises(AzspError):
