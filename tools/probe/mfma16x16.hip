@@ -44,6 +44,24 @@ __global__ void k_dep(int n, unsigned long long *out, float *sink) {
     if (s == 1234.5f) sink[0] = s;
 }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+// v_mfma_f32_32x32x16_f16 (the split-fp16 kernel): NACC accumulators round-robin
+template <int NACC>
+__global__ void k_dep16(int n, unsigned long long *out, float *sink) {
+    f32x16 a[NACC];
+    for (int i = 0; i < NACC; ++i) for (int v = 0; v < 16; ++v) a[i][v] = 0;
+    h8 x, y;
+    for (int k = 0; k < 8; ++k) { x[k] = (_Float16)(threadIdx.x * 1e-3f); y[k] = (_Float16)1.0f; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < n; i += 24)
+#pragma unroll
+        for (int k = 0; k < 24; ++k) a[k % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a[k % NACC], 0, 0, 0);
+    float s = 0;
+    for (int i = 0; i < NACC; ++i) for (int v = 0; v < 16; ++v) s += a[i][v];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) out[0] = t1 - t0;
+    if (s == 1234.5f) sink[0] = s;
+}
 __global__ void k_rate32(int n, unsigned long long *out, float *sink) {
     f32x16 a[4];
     for (int i = 0; i < 4; ++i) for (int v = 0; v < 16; ++v) a[i][v] = 0;
@@ -73,13 +91,16 @@ int main() {
             bad += r != hD[m * 16 + n];
         }
     printf("layout: %d mismatches of 256\n", bad);
-    const int N = 100000;
+    const int N = 96000;
     k_rate<<<1, 64>>>(N, dt, dD); k_rate<<<1, 64>>>(N, dt, dD);
     hipMemcpy(&ht, dt, 8, hipMemcpyDeviceToHost);
     printf("rate: %.2f ticks per v_mfma_f32_16x16x4_f32 (the 64-cycle 32x32x2 form measures 72 of these ticks)\n", (double)ht / N);
 #define DEP(NA) k_dep<NA><<<1, 64>>>(N, dt, dD); k_dep<NA><<<1, 64>>>(N, dt, dD); hipMemcpy(&ht, dt, 8, hipMemcpyDeviceToHost); \
     printf("dependent chains, %d accumulators round-robin: %.2f ticks per MFMA\n", NA, (double)ht / N);
     DEP(1) DEP(2) DEP(4) DEP(5)
+#define DEP16(NA) k_dep16<NA><<<1, 64>>>(N, dt, dD); k_dep16<NA><<<1, 64>>>(N, dt, dD); hipMemcpy(&ht, dt, 8, hipMemcpyDeviceToHost); \
+    printf("v_mfma_f32_32x32x16_f16, %d accumulators round-robin: %.2f ticks per MFMA\n", NA, (double)ht / N);
+    DEP16(1) DEP16(2) DEP16(3) DEP16(4)
     k_rate32<<<1, 64>>>(N, dt, dD); k_rate32<<<1, 64>>>(N, dt, dD);
     hipMemcpy(&ht, dt, 8, hipMemcpyDeviceToHost);
     printf("rate: %.2f ticks per v_mfma_f32_32x32x2_f32 (20 per loop iteration, 4 accumulators)\n", (double)ht / N);
