@@ -507,19 +507,26 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         logits[tid] = sum + (o < 7 ? (o < A ? P.fcp_b[o] : 0.0f) : P.fcv_b[0]);
     }
     __syncthreads();
-    if (tid < TB && board0 + tid < n_leaf) {
-        const int j = board0 + tid;
-        const int slot = leaf_slot[j];
-        const uint32_t legal = G::legal_mask(mine[(size_t)slot * bstride], theirs[(size_t)slot * bstride]);
-        float mx = -INFINITY;
+    // masked softmax + tanh on eight lanes per board, as in the fp32 kernel (one lane per action, the eighth holds the value
+    // logit; the denominator is summed in action order)
+    if (tid < TB * 8) {
+        const int b = tid >> 3, a = tid & 7;
+        const bool liveb = board0 + b < n_leaf;
+        const int slot = liveb ? leaf_slot[board0 + b] : 0;
+        const uint32_t legal = liveb ? G::legal_mask(mine[(size_t)slot * bstride], theirs[(size_t)slot * bstride]) : 0u;
+        const bool leg = a < A && ((legal >> a) & 1u);
+        const float x = logits[b * 8 + a];
+        float mx = leg ? x : -INFINITY;
 #pragma unroll
-        for (int a = 0; a < A; ++a) if ((legal >> a) & 1u) mx = fmaxf(mx, logits[tid * 8 + a]);
-        float ex[A], den = 0.0f;
+        for (int m = 1; m < 8; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 8));
+        const float ex = leg ? expf(x - mx) : 0.0f;
+        float den = 0.0f;
 #pragma unroll
-        for (int a = 0; a < A; ++a) { ex[a] = ((legal >> a) & 1u) ? expf(logits[tid * 8 + a] - mx) : 0.0f; den += ex[a]; }
-#pragma unroll
-        for (int a = 0; a < Connect4::AP; ++a) out_p[(size_t)slot * p_stride + a] = a < A ? ex[a < A ? a : 0] / den : 0.0f;
-        out_v[(size_t)slot * v_stride] = tanhf(logits[tid * 8 + 7]);
+        for (int k = 0; k < A; ++k) den += __shfl(ex, k, 8);
+        if (liveb) {
+            out_p[(size_t)slot * p_stride + a] = leg ? ex / den : 0.0f;
+            if (a == 7) out_v[(size_t)slot * v_stride] = tanhf(x);
+        }
     }
     STAMP16(55);
 }
