@@ -115,7 +115,7 @@ class Engine:
         return p, v
 
     def probe_clock(self, boards) -> tuple[float, float]:
-        """(GHz the chip held inside one traced fp32 inference launch over `boards`, span of that launch in us)."""
+        """(GHz the chip held inside one traced inference launch over `boards` -- fp32 or f16x2 kernel, 64 channels --, span of that launch in us)."""
         b = self._boards_i8(boards)
         ghz, span = C.c_double(), C.c_double()
         self._check(self.lib.azsp_probe_clock(self._h, _ptr(b, C.c_int8), b.shape[0], C.byref(ghz), C.byref(span)))

@@ -738,9 +738,8 @@ int azsp_predict(azsp_engine *e, const int8_t *boards, int32_t n, float *p_out, 
 
 int azsp_probe_clock(azsp_engine *e, const int8_t *boards, int32_t n, double *clock_ghz, double *span_us) {
     if (!e || !boards || n <= 0 || n > e->cfg.n_slots) return fail(AZSP_ERR_ARG, "bad argument");
-    if (e->evaluator != AZSP_EVAL_RESNET || (e->cfg.flags & AZSP_FLAG_F16_SPLIT) || e->cfg.game != AZSP_GAME_CONNECT4 ||
-        e->cfg.channels > 64 || e->cfg.channels <= 32)
-        return fail(AZSP_ERR_STATE, "the clock probe exists for the 64-channel fp32 Connect-4 network");
+    if (e->evaluator != AZSP_EVAL_RESNET || e->cfg.game != AZSP_GAME_CONNECT4 || e->cfg.channels > 64 || e->cfg.channels <= 32)
+        return fail(AZSP_ERR_STATE, "the clock probe exists for the 64-channel Connect-4 network (fp32 and f16x2 kernels)");
     resnet_trace_next();
     int rc = azsp_predict(e, boards, n, nullptr, nullptr);
     if (rc) return rc;

@@ -29,6 +29,10 @@
 
 namespace azsp {
 
+// tracing state shared with the fp32 kernel (azsp_resnet.hip)
+bool resnet_trace_wanted(bool *print);
+void resnet_trace_report(const unsigned long long *stamps, int grid, bool print);
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -400,6 +404,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     }
     __syncthreads();
     STAMP16(2);
+    if constexpr ((ABL & 8) != 0) { if (tid == 0) P.dbg[(size_t)blockIdx.x * 64 + 56] = __builtin_amdgcn_s_memtime(); }   // core-clock counter
 
     // ---- residual blocks ---------------------------------------------------------------------------------
     // 64 channels on the 2 x 2 wave grid: the statically scheduled tower (nine taps per layer, so the two weight
@@ -441,6 +446,9 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         if (layer < 16) STAMP16(5 + 3 * layer);
     }
 
+    if constexpr ((ABL & 8) != 0) {
+        if (tid == 0) { P.dbg[(size_t)blockIdx.x * 64 + 57] = __builtin_amdgcn_s_memtime(); P.dbg[(size_t)blockIdx.x * 64 + 58] = wall_clock64(); }
+    }
     // ---- heads: policy 1x1 and value 3x3 convs, one 32-wide column tile each; the row tiles of a row
     //      group are dealt round-robin to its CT waves -----------------------------------------------------
     f32x16 accp[PT], accv[PT];
@@ -752,8 +760,8 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
     switch (n->CT) {
         case 1: if (wr_env == 8 || (!wr_env && max_leaves <= 768)) L16(1, 8); else L16(1, 4); break;
         case 2: {
-            static const bool trace = getenv("AZSP_RESNET_TRACE") != nullptr;
-            if (trace) {     // diagnostic instantiation with per-phase timestamps (prints like the fp32 kernel's trace)
+            bool print = false;
+            if (resnet_trace_wanted(&print)) {     // diagnostic instantiation with the fp32 kernel's stamps: phase times, in-kernel clock
                 constexpr int TBB = F16_ROWS / Connect4::CELLS;
                 const int grid = (max_leaves + TBB - 1) / TBB;
                 unsigned long long *dd = nullptr;
@@ -767,26 +775,7 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
                     std::vector<unsigned long long> h(cnt);
                     (void)hipMemcpy(h.data(), dd, cnt * 8, hipMemcpyDeviceToHost);
                     (void)hipFree(dd);
-                    static int calls = 0;
-                    if (++calls <= 3) {
-                        double sum[64] = {};
-                        int ran = 0;
-                        unsigned long long t0 = ~0ull, t1 = 0;
-                        for (int w = 0; w < grid; ++w) {
-                            const unsigned long long *t = &h[(size_t)w * 64];
-                            if (!t[55]) continue;
-                            ++ran;
-                            t0 = t[0] < t0 ? t[0] : t0;
-                            t1 = t[55] > t1 ? t[55] : t1;
-                            unsigned long long prev = t[0];
-                            for (int k = 1; k < 56; ++k) if (t[k]) { sum[k] += (double)(t[k] - prev); prev = t[k]; }
-                        }
-                        if (ran) {
-                            fprintf(stderr, "[azsp trace f16x2] %d workgroups, span %.1f us; mean phase durations (us):", ran, (t1 - t0) * 0.01);
-                            for (int k = 1; k < 56; ++k) if (sum[k] > 0) fprintf(stderr, " %d:%.2f", k, sum[k] / ran * 0.01);
-                            fprintf(stderr, "\n");
-                        }
-                    }
+                    resnet_trace_report(h.data(), grid, print);      // keeps clock and span for azsp_probe_clock
                     break;
                 }
             }

@@ -280,11 +280,11 @@ def main() -> None:
             "tree": tree_report(st, dt, n_act),
         }
 
-    head = measure(args.precision)
-    if (args.precision == "f32" and args.game == "connect4" and 32 < args.channels <= 64 and rank == 0 and not args.no_clock_probe):
-        # The peak assumes the nominal 2.4 GHz; what the chip holds under this kernel is measured right after the timed
-        # region with the stamped diagnostic instantiation: 2000 untraced launches (about 1.5 s) of 3072 mid-game
-        # boards (two workgroups per CU, like the overlapping launches of the run), then one traced launch.
+    def probe_clock(result, precision):
+        """The peaks assume the nominal 2.4 GHz; what the chip holds under the kernel is measured right after the timed
+        region with the stamped diagnostic instantiation: 2000 untraced launches (about 1.5 s) of 3072 mid-game boards
+        (two workgroups per CU, like the overlapping launches of the run), then one traced launch."""
+        rl = result["roofline"]
         try:
             from azsp.engine import Engine
             from azsp.weights import resnet_blob
@@ -294,22 +294,32 @@ def main() -> None:
                 for c in range(7):
                     h = rng.randint(0, 6)
                     b[6 - h:, c] = rng.choice([-1, 1], size=h)
-            with Engine("connect4", 3072, 1, device=local_rank, res_blocks=args.blocks, channels=args.channels) as pe:
+            with Engine("connect4", 3072, 1, device=local_rank, res_blocks=args.blocks, channels=args.channels,
+                        f16_split=(precision == "f16x2")) as pe:
                 pe.load_resnet(resnet_blob(net)[0])
                 for _ in range(2000):
                     pe.predict(pb)
                 ghz, span = pe.probe_clock(pb)
-            rl = head["roofline"]
             rl["held_clock_ghz"] = ghz
             rl["peak_at_held_clock"] = rl["peak"] * ghz / 2.4
             rl["frac_at_held_clock"] = rl["achieved"] / rl["peak_at_held_clock"]
-            rl["executed_frac_at_held_clock"] = rl["frac_at_held_clock"] * rl["executed_flops_per_board"] / rl["flops_per_board"]
+            # f16x2 executes three fp16 MFMAs per algorithmic multiply-add (hi*hi, hi*lo, lo*hi)
+            rl["executed_frac_at_held_clock"] = (rl["frac_at_held_clock"] * rl["executed_flops_per_board"] / rl["flops_per_board"]
+                                                 * (3.0 if precision == "f16x2" else 1.0))
         except Exception as exc:        # noqa: BLE001  the probe is an extra, never a reason to lose the bench line
-            head["roofline"]["held_clock_ghz"] = None
-            head["roofline"]["held_clock_error"] = str(exc)
+            rl["held_clock_ghz"] = None
+            rl["held_clock_error"] = str(exc)
+
+    probe_ok = args.game == "connect4" and 32 < args.channels <= 64 and rank == 0 and not args.no_clock_probe
+    head = measure(args.precision)
+    if probe_ok:
+        probe_clock(head, args.precision)
     other = None
     if not args.single:
-        other = measure("f16x2" if args.precision == "f32" else "f32")
+        other_precision = "f16x2" if args.precision == "f32" else "f32"
+        other = measure(other_precision)
+        if probe_ok:
+            probe_clock(other, other_precision)
 
     if rank == 0:
         out = {

@@ -236,11 +236,12 @@ int32_t azsp_record_bytes(int32_t game);
 int64_t azsp_export_dataset_device(azsp_engine *e, int64_t first, int64_t n, float *planes, float *policies,
                                    float *values, int64_t cap_samples);
 
-/* Measurement aid: evaluates n (<= n_slots) boards once with the diagnostic instantiation of the fp32 kernel that
- * stamps s_memtime / s_memrealtime around the residual tower, and returns the clock the chip held inside the kernel
- * (GHz) and the launch's span (us).  The roofline peak assumes the nominal 2.4 GHz; what the chip really holds under
- * the kernel is a measurement.  Call it after >= 100 launches in the same process: the first
- * launches of a process run while the clock is still ramping up.  64-channel fp32 Connect-4 only. */
+/* Measurement aid: evaluates n (<= n_slots) boards once with the diagnostic instantiation of the engine's inference
+ * kernel (fp32, or f16x2 with AZSP_FLAG_F16_SPLIT) that stamps s_memtime / s_memrealtime around the residual tower, and
+ * returns the clock the chip held inside the kernel (GHz) and the launch's span (us).  The roofline peaks assume the
+ * nominal 2.4 GHz; what the chip really holds under the kernel is a measurement (2.35 GHz under
+ * the fp32 kernel, 1.75-1.8 GHz under the fp16 MFMAs).  Call it after >= 100 launches in the same process: the first
+ * launches of a process run while the clock is still ramping up.  64-channel Connect-4 only. */
 int  azsp_probe_clock(azsp_engine *e, const int8_t *boards, int32_t n, double *clock_ghz, double *span_us);
 int  azsp_get_stats(azsp_engine *e, azsp_stats *out);
 int  azsp_reset_stats(azsp_engine *e);
