@@ -1014,6 +1014,16 @@ def test_clock_probe_reports_a_plausible_in_kernel_clock(azsp):
         p1, v1 = e.predict(boards)
     assert 1.5 < ghz < 2.6 and 50.0 < span < 5000.0
     assert np.array_equal(p0, p1) and np.array_equal(v0, v1)      # the probe leaves the engine as it was
+    with _engine(azsp, "connect4", 1536, 1, res_blocks=4, channels=64, f16_split=True) as e:      # the split-fp16 kernel's stamped form
+        e.load_resnet(blob)
+        q0, w0 = e.predict(boards)
+        for _ in range(300):
+            e.predict(boards)
+        ghz16, span16 = e.probe_clock(boards)
+        q1, w1 = e.predict(boards)
+    print(f"held clock: fp32 kernel {ghz:.3f} GHz, f16x2 kernel {ghz16:.3f} GHz")
+    assert 1.2 < ghz16 < 2.6 and 20.0 < span16 < 5000.0
+    assert np.array_equal(q0, q1) and np.array_equal(w0, w1)
     with _engine(azsp, "connect4", 64, 1, hash_salt=1) as e:
         e.use_hash_evaluator()
         with pytest.raises(Exception):
