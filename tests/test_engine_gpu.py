@@ -295,6 +295,42 @@ def test_baseline_networks_within_north_star_tolerance(azsp, game, blocks, ch):
         assert np.all(p[mask == 0] == 0)
 
 
+@pytest.mark.parametrize("blocks,ch", [(2, 32), (2, 64), (2, 96), (3, 128), (1, 192), (2, 256)])
+def test_gomoku_network_geometries_against_torch(azsp, blocks, ch):
+    """Every Gomoku kernel geometry -- three boards per workgroup up to 64 channels; from 96 on one board per workgroup on
+    five 16-row MFMA tiles plus the corner cell on the vector ALU (chunks of 6 or 8 sixteen-channel groups), Linear layer in
+    channel slices, value conv in channel slices, softmax on a wave -- against the module's float32 PyTorch forward, with
+    non-trivial BatchNorm statistics; batch sizes that leave workgroups partly filled and empty."""
+    import torch
+    from azsp.weights import resnet_blob
+    torch.manual_seed(100 * blocks + ch)
+    net = azsp.ResNet((9, 9), 81, blocks, ch)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    net.eval()
+    rules = oz.G9Rules()
+    boards = random_midgame_boards(rules, np.random.RandomState(ch), 40, 60)
+    boards.append(np.zeros((9, 9), np.int8))                      # the empty board: every tap of every cell multiplies zeros
+    full = np.ones((9, 9), np.int8); full[::2, 1::2] = -1; full[8, 8] = 0
+    boards.append(full)                                           # one legal move: the corner cell
+    pt, vt, mask = _torch_reference(net, rules, boards)
+    blob = resnet_blob(net)[0]
+    with _engine(azsp, "gomoku9", 64, 1, res_blocks=blocks, channels=ch) as e:
+        e.load_resnet(blob)
+        p, v = e.predict(np.stack(boards))
+        p1, v1 = e.predict(np.stack(boards[:7]))                  # bits do not depend on the batch
+    err_p, err_v = np.max(np.abs(p - pt)), np.max(np.abs(v - vt))
+    print(f"[net-error] gomoku9 {blocks}x{ch}: max |dp| = {err_p:.2e}, max |dv| = {err_v:.2e} vs torch f32")
+    assert err_p < NET_TOL_WIDE and err_v < NET_TOL_WIDE
+    assert np.all(p[mask == 0] == 0) and p[-1][80] == 1.0
+    assert np.array_equal(p[:7], p1) and np.array_equal(v[:7], v1)
+
+
 @pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
 @pytest.mark.parametrize("blocks,ch", [(4, 64), (2, 128), (2, 32)])
 def test_resnet_every_batch_regime_returns_the_same_bits(azsp, blocks, ch, f16):
