@@ -16,15 +16,16 @@ EVAL_RESNET, EVAL_HASH, EVAL_HOST = 0, 1, 2
 FLAG_TIMING = 1
 FLAG_F16_SPLIT = 2
 FLAG_TREE_REUSE = 4
+FLAG_EVAL_CACHE = 8
 RULES_SIMPLE, RULES_GEN1, RULES_SIMPLE_NUMPY1 = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("game", C.c_int32), ("n_slots", C.c_int32), ("n_sims", C.c_int32),
                 ("device", C.c_int32), ("res_blocks", C.c_int32), ("channels", C.c_int32), ("flags", C.c_uint32),
                 ("hash_salt", C.c_uint64), ("n_groups", C.c_int32), ("arena_episodes", C.c_int32),
-                ("search_rules", C.c_int32), ("reserved", C.c_int32)]
+                ("search_rules", C.c_int32), ("eval_cache_entries", C.c_int32)]
 
 
 class PlyResult(C.Structure):
@@ -38,7 +39,8 @@ class Stats(C.Structure):
                 ("terminal_leaves", C.c_uint64), ("infer_launches", C.c_uint64), ("infer_ms", C.c_double),
                 ("infer_boards", C.c_uint64), ("select_ms", C.c_double), ("expand_ms", C.c_double),
                 ("play_ms", C.c_double), ("select_launches", C.c_uint64), ("expand_launches", C.c_uint64),
-                ("path_nodes", C.c_uint64), ("infer_union_ms", C.c_double)]
+                ("path_nodes", C.c_uint64), ("infer_union_ms", C.c_double), ("evals_executed", C.c_uint64),
+                ("infer_exec_flops_per_board", C.c_double), ("eval_cache_entries", C.c_uint64)]
 
 
 class SearchOptions(C.Structure):

@@ -22,7 +22,8 @@ class EpisodeGenerator:
     def __init__(self, *, game, config: AlphaZeroConfig, device: int | None = None, timing: bool = False,
                  n_groups: int = 0, f16_split: bool = False, sampling_plies: int | None = None,
                  dirichlet_alpha: float | None = None, dirichlet_eps: float = 0.25, c_init: float = 1.0,
-                 c_base: float = 0.0, numpy1_value_sums: bool = False, tree_reuse: bool = False):
+                 c_base: float = 0.0, numpy1_value_sums: bool = False, tree_reuse: bool = False, eval_cache: bool = False,
+                 eval_cache_entries: int = 0):
         self.game = game
         self.config = config
         self.device = device
@@ -37,6 +38,9 @@ class EpisodeGenerator:
         self.numpy1_value_sums = numpy1_value_sums
         # True: keep the chosen child's subtree (and its statistics) as the next ply's tree (AZSP_FLAG_TREE_REUSE)
         self.tree_reuse = tree_reuse
+        # True: every position is evaluated at most once per generate_episodes call (AZSP_FLAG_EVAL_CACHE): a position ->
+        # (p, v) table in HBM; identical episodes, fewer network evaluations (Connect-4 / Connect2, device evaluators)
+        self.eval_cache, self.eval_cache_entries = eval_cache, eval_cache_entries
         self.f16_split = f16_split    # device ResNet on the fp16 matrix pipe with split operands (fp32-class accuracy)
         self.n_groups = n_groups      # concurrent slot groups (HIP streams); 0 = automatic; never changes results
         self._engine: Engine | None = None
@@ -45,7 +49,8 @@ class EpisodeGenerator:
 
     def engine_for(self, model) -> Engine:
         blocks, ch, salt = engine_geometry_for_model(model, self.game)
-        key = (self.config.num_episodes, self.config.num_simulations, blocks, ch, salt, self.f16_split, self.numpy1_value_sums, self.tree_reuse)
+        key = (self.config.num_episodes, self.config.num_simulations, blocks, ch, salt, self.f16_split, self.numpy1_value_sums, self.tree_reuse,
+               self.eval_cache, self.eval_cache_entries)
         if self._engine is None or key != self._engine_key:
             if self._engine is not None:
                 self._engine.close()
@@ -53,7 +58,8 @@ class EpisodeGenerator:
             self._engine = Engine(self.game, self.config.num_episodes, self.config.num_simulations, device=dev,
                                   res_blocks=blocks, channels=ch, timing=self.timing, hash_salt=salt,
                                   n_groups=self.n_groups, f16_split=self.f16_split,
-                                  search_rules=2 if self.numpy1_value_sums else 0, tree_reuse=self.tree_reuse)
+                                  search_rules=2 if self.numpy1_value_sums else 0, tree_reuse=self.tree_reuse,
+                                  eval_cache=self.eval_cache, eval_cache_entries=self.eval_cache_entries)
             self._engine_key = key
         configure_engine_for_model(self._engine, model)
         return self._engine

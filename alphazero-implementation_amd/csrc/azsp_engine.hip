@@ -109,13 +109,14 @@ struct azsp_engine {
     float *d_stage_p = nullptr, *d_stage_v = nullptr;   // host evaluator: results in list order before the scatter to slots
     size_t leaf_off = 0;              // byte offset of the leaf position inside a slot record
     int32_t eval_off = -1;            // byte offset of the evaluator's row inside a slot record, -1 = separate arrays
-    // AZSP_GRAPH=1 at engine creation: the launches of one ply's search (a fixed sequence for a given number of active
-    // slots and engine state) are captured once into a HIP graph and replayed
-    struct SearchGraph { int n_act; unsigned epoch; hipGraphExec_t exec; azsp_stats delta; uint64_t rounds; };
-    std::vector<SearchGraph> graphs;
-    bool graph_mode = false, graph_warm = false;
-    unsigned epoch = 0;               // bumped by whatever changes what a search enqueues (evaluator, weights, options)
-    int fused_rounds_mode = 2;        // AZSP_FUSED_ROUNDS at engine creation: 0 never, 1 wherever a fused kernel exists, unset = 2: up to 32 games only
+    // diagnostics switches (AZSP_DIAG, read once at engine creation; include/azsp.h): the product defaults are both true
+    bool fused_rounds_small = true;   // up to 32 games: one launch per simulation round (one-board kernels with the tree step fused in)
+    bool fused_tree = true;           // device evaluators: expansion of round r-1 and descent of round r as ONE launch
+    // evaluation cache (AZSP_FLAG_EVAL_CACHE): n_slots private entries + ent_table (power of two) hashed ones
+    EvalEnt *d_ent = nullptr;
+    size_t ent_table = 0;
+    int ent_shift = 0, ent_epoch = 0;
+    int last_infer_cap = 0;           // board capacity of the most recent inference launch (selects the kernel variant)
     double *d_st_wd = nullptr, *d_st_rwd = nullptr;   // float64 root statistics staging
     double *d_sqrt = nullptr, *d_ctab = nullptr, *d_expl = nullptr;   // [n_sims + 2] exploration tables
     double c_init = 1.0, c_base = 0.0;
@@ -210,9 +211,17 @@ static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
         case AZSP_EVAL_RESNET: {
             if (!e->net || !e->net_loaded) return fail(AZSP_ERR_STATE, "ResNet evaluator selected but no weights loaded (azsp_load_resnet)");
             EventPair *p = ev_begin(e, EV_INFER, st);
-            // leaf positions sit in the slot records; outputs are indexed by slot, so groups never share rows
-            resnet_forward(e->net, game, reinterpret_cast<const u64 *>(v.slot + e->leaf_off), v.slot_bytes / 8, v.leaf_slot + v.lo, v.nl,
-                           v.n_act, v.eval_p, v.eval_pstride, v.eval_v, v.eval_vstride, st);
+            e->last_infer_cap = v.n_act;
+            if (v.ent != nullptr) {
+                // evaluation cache: the list holds entries; positions are read from and rows written into them
+                float *row0 = v.ent[0].row;
+                resnet_forward(e->net, game, &v.ent[0].mine, (int)(sizeof(EvalEnt) / 8), v.leaf_slot + v.lo, v.nl, v.n_act, row0,
+                               (int)(sizeof(EvalEnt) / 4), row0 + 7, (int)(sizeof(EvalEnt) / 4), st);
+            } else {
+                // leaf positions sit in the slot records; outputs are indexed by slot, so groups never share rows
+                resnet_forward(e->net, game, reinterpret_cast<const u64 *>(v.slot + e->leaf_off), v.slot_bytes / 8, v.leaf_slot + v.lo, v.nl,
+                               v.n_act, v.eval_p, v.eval_pstride, v.eval_v, v.eval_vstride, st);
+            }
             ev_end(p, st);
             e->stats.infer_launches++;
             return 0;
@@ -251,6 +260,19 @@ static int search_enqueue(azsp_engine *e, int n_act) {
     const int game = e->cfg.game;
     int G = e->n_groups;
     if (e->evaluator == AZSP_EVAL_HOST || n_act < 64 * G) G = 1;
+    // Device evaluators: expansion of round s-1 and descent of round s run as ONE launch that appends its leaves with a
+    // wave-level atomic (two launches per round).  The host-callback evaluator keeps the stable, slot-ordered
+    // select -> compact -> evaluate -> expand sequence (the reference hands its leaves over in slot order).
+    const bool fused = e->fused_tree && e->evaluator != AZSP_EVAL_HOST;
+    // FUSED rounds (a few games, one-board kernels of the exact-fp32 Connect-4 network, rule set 0): ONE launch per round
+    // and group -- the inference kernel expands the leaf it evaluated and finds the game's next leaf itself (a game whose
+    // descent ends on a terminal leaf backs it up and descends again in the same launch).  Round r reads list r & 1 /
+    // counter r % 3, fills list (r + 1) & 1 / counter (r + 1) % 3 and clears counter (r + 2) % 3.  Bit-exact (tested).
+    // Only up to 32 games, where a round is launch latency (one game 106.6 -> 101.0 us per round); for large batches the
+    // same idea measured SLOWER (2101 against 2209 episodes/s: the tree step is a chain of dependent loads during which
+    // the workgroup's other waves idle) and its kernels were retired after round 2.
+    bool fused_rounds = e->fused_rounds_small && e->evaluator == AZSP_EVAL_RESNET && e->net && e->net_loaded &&
+                        e->cfg.search_rules == AZSP_RULES_SIMPLE && !e->v.reuse && e->v.root_noise == nullptr;
     View gv[MAX_GROUPS];
     for (int k = 0; k < G; ++k) {
         gv[k] = e->v;
@@ -260,28 +282,36 @@ static int search_enqueue(azsp_engine *e, int n_act) {
         gv[k].lo = (int)((long long)n_act * k / G);
         gv[k].n_act = (int)((long long)n_act * (k + 1) / G) - gv[k].lo;
     }
+    for (int k = 0; k < G && fused_rounds; ++k) fused_rounds = resnet_has_fused(e->net, game, gv[k].n_act, e->v.tab_lds);
+    // Evaluation cache (AZSP_FLAG_EVAL_CACHE; protocol in azsp_internal.h): needs a deterministic device evaluator and
+    // the fused tree launches; every search gets the next epoch number (the table is cleared when they run out).
+    const bool cache = e->d_ent != nullptr && fused && !fused_rounds;
+    if (cache) {
+        if (++e->ent_epoch > 4095) {
+            HIP_TRY(hipMemsetAsync(e->d_ent, 0, (e->ent_table + (size_t)e->cfg.n_slots) * sizeof(EvalEnt), e->stream));
+            e->ent_epoch = 1;
+        }
+        for (int k = 0; k < G; ++k) {
+            gv[k].ent = e->d_ent;
+            gv[k].ent_mask = (uint32_t)(e->ent_table - 1);
+            gv[k].ent_shift = e->ent_shift;
+            gv[k].ent_epoch = e->ent_epoch;
+        }
+    }
     if (G > 1) {
         HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
         for (int k = 1; k < G; ++k) HIP_TRY(hipStreamWaitEvent(e->gstream[k], e->ev_fork, 0));
     }
-    // FUSED rounds (AZSP_FUSED_ROUNDS=1 at engine creation; exact-fp32 device network, Connect-4, rule set 0, large
-    // groups): ONE launch per round and group -- the inference kernel expands the leaves it evaluated and finds those
-    // games' next leaves itself (a game whose descent ends on a terminal leaf backs it up and descends again in the same
-    // launch), so there is no tree launch, no gap and no evaluator output in HBM.  Round r reads list r & 1 / counter
-    // r % 3, fills list (r + 1) & 1 / counter (r + 1) % 3 and clears counter (r + 2) % 3 (the one the previous launch
-    // read).  Bit-exact (tested).  The default for a FEW games (up to 32, one-board kernels): there a round is launch
-    // latency and one launch instead of two is 3-5 % less of it.  NOT the default otherwise: measured 2101 against 2209
-    // episodes/s at the headline (128 channels: 290 against 294) -- the tree step is a chain of dependent loads during
-    // which the workgroup's other three waves idle while it keeps one of the CU's two workgroup slots, so both residents are
-    // outside their towers more often and the matrix pipe idles more than the removed launches had cost.
-    bool fused_rounds = e->fused_rounds_mode != 0 && e->evaluator == AZSP_EVAL_RESNET && e->net && e->net_loaded &&
-                        e->cfg.search_rules == AZSP_RULES_SIMPLE && !e->v.reuse && e->v.root_noise == nullptr;
-    for (int k = 0; k < G && fused_rounds; ++k)
-        fused_rounds = resnet_has_fused(e->net, game, gv[k].n_act, e->fused_rounds_mode == 2, e->v.tab_lds);
     for (int k = 0; k < G; ++k) {
         hipStream_t st = e->gstream[k];
-        launch_root_prepare(game, gv[k], st);
-        launch_compact(gv[k], st);
+        if (cache) {
+            // the roots join the list from k_root_prepare (entries, claimed once per position): zero its counters first
+            HIP_TRY(hipMemsetAsync(gv[k].nl, 0, 4 * sizeof(int32_t), st));
+            launch_root_prepare(game, gv[k], st);
+        } else {
+            launch_root_prepare(game, gv[k], st);
+            launch_compact(gv[k], st);
+        }
         if (fused_rounds) continue;              // the roots are evaluated by round 0
         int rc = evaluate_leaves(e, gv[k], st);
         if (rc) return rc;
@@ -315,11 +345,6 @@ static int search_enqueue(azsp_engine *e, int n_act) {
     }
     // rule set 1: the root expansion is simulation 1 (search.py:66-91)
     const int descents = e->cfg.search_rules == AZSP_RULES_GEN1 ? e->cfg.n_sims - 1 : e->cfg.n_sims;
-    // Device evaluators: expansion of round s-1 and descent of round s run as ONE launch that appends its leaves with a
-    // wave-level atomic (two launches per round).  The host-callback evaluator keeps the stable, slot-ordered
-    // select -> compact -> evaluate -> expand sequence (the reference hands its leaves over in slot order).
-    static const bool fused_env = [] { const char *x = getenv("AZSP_FUSED_TREE"); return !x || atoi(x) != 0; }();
-    const bool fused = fused_env && e->evaluator != AZSP_EVAL_HOST;
     if (!fused)
         for (int k = 0; k < G; ++k) launch_expand(game, gv[k], e->gstream[k]);
     for (int s = 0; s < descents; ++s) {
@@ -376,47 +401,14 @@ static int search_enqueue(azsp_engine *e, int n_act) {
     return 0;
 }
 
-// One ply's search.  With AZSP_GRAPH=1 the second search of a given shape is captured from the engine's streams (the
-// group streams fork from and join the main stream through events, which capture follows) and every later one is ONE
-// graph launch; the timing flag (events read back later) and the host-callback evaluator (synchronises) keep streams.
-static int search(azsp_engine *e, int n_act) {
-    if (!e->graph_mode || (e->cfg.flags & AZSP_FLAG_TIMING) || e->evaluator == AZSP_EVAL_HOST || e->v.root_noise != nullptr)
-        return search_enqueue(e, n_act);
-    for (auto &g : e->graphs)
-        if (g.n_act == n_act && g.epoch == e->epoch) {
-            HIP_TRY(hipGraphLaunch(g.exec, e->stream));
-            e->stats.plies += g.delta.plies;
-            e->stats.select_launches += g.delta.select_launches;
-            e->stats.expand_launches += g.delta.expand_launches;
-            e->stats.infer_launches += g.delta.infer_launches;
-            e->rounds_host += g.rounds;
-            e->v.lo = 0; e->v.grp = 0; e->v.n_act = n_act;
-            e->searched = true;
-            return 0;
-        }
-    if (!e->graph_warm) { e->graph_warm = true; return search_enqueue(e, n_act); }      // first: let every kernel set itself up
-    const azsp_stats before = e->stats;
-    const uint64_t rounds_before = e->rounds_host;
-    hipGraph_t graph = nullptr;
-    HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = search_enqueue(e, n_act);
-    const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
-    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (ce != hipSuccess || !graph) return fail(AZSP_ERR_HIP, "graph capture of a search failed: %s", hipGetErrorString(ce));
-    azsp_engine::SearchGraph g{};
-    g.n_act = n_act;
-    g.epoch = e->epoch;
-    const hipError_t ie = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ie != hipSuccess) return fail(AZSP_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
-    g.delta.plies = e->stats.plies - before.plies;
-    g.delta.select_launches = e->stats.select_launches - before.select_launches;
-    g.delta.expand_launches = e->stats.expand_launches - before.expand_launches;
-    g.delta.infer_launches = e->stats.infer_launches - before.infer_launches;
-    g.rounds = e->rounds_host - rounds_before;
-    if (e->graphs.size() >= 4) { (void)hipGraphExecDestroy(e->graphs.front().exec); e->graphs.erase(e->graphs.begin()); }
-    e->graphs.push_back(g);
-    HIP_TRY(hipGraphLaunch(g.exec, e->stream));          // the capture enqueued nothing: this is the search itself
+static int search(azsp_engine *e, int n_act) { return search_enqueue(e, n_act); }
+
+// A new generation run, new weights or another evaluator: every cached row is void.  (Cleared on the main stream, which
+// every search forks from.)
+static int cache_clear(azsp_engine *e) {
+    if (!e->d_ent) return 0;
+    HIP_TRY(hipMemsetAsync(e->d_ent, 0, (e->ent_table + (size_t)e->cfg.n_slots) * sizeof(EvalEnt), e->stream));
+    e->ent_epoch = 0;
     return 0;
 }
 
@@ -487,7 +479,6 @@ void azsp_destroy(azsp_engine *e) {
         if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
         if (e->gstream[k]) (void)hipStreamDestroy(e->gstream[k]);
     }
-    for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     if (e->net) resnet_destroy(e->net);
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->h_res) (void)hipHostFree(e->h_res);
@@ -517,8 +508,10 @@ static int create_impl(azsp_engine *e) {
     const azsp_config &c = e->cfg;
     const GameInfo &gi = e->gi;
     ON_DEVICE(c.device);
-    { const char *x = getenv("AZSP_FUSED_ROUNDS"); e->fused_rounds_mode = x ? (atoi(x) != 0 ? 1 : 0) : 2; }
-    { const char *x = getenv("AZSP_GRAPH"); e->graph_mode = x && atoi(x) != 0; }
+    if (const char *x = getenv("AZSP_DIAG")) {       // diagnostics switches (include/azsp.h), read once per engine
+        e->fused_rounds_small = strstr(x, "no_fused_rounds") == nullptr;
+        e->fused_tree = strstr(x, "unfused_tree") == nullptr;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->gstream[0] = e->stream;
     e->n_groups = c.n_groups > 0 ? (c.n_groups > MAX_GROUPS ? MAX_GROUPS : c.n_groups) : (c.n_slots >= 3072 ? 3 : (c.n_slots >= 1024 ? 2 : 1));
@@ -607,6 +600,21 @@ static int create_impl(azsp_engine *e) {
     DEV_ALLOC(e->d_noise, (size_t)N * A);
     DEV_ALLOC(e->d_st_wd, (size_t)N * A); DEV_ALLOC(e->d_st_rwd, N);
 
+    if (c.flags & AZSP_FLAG_EVAL_CACHE) {
+        if (gi.W != 1 || AP != 8)
+            return fail(AZSP_ERR_ARG, "AZSP_FLAG_EVAL_CACHE needs a game whose positions have an injective 64-bit key (Connect-4, Connect2)");
+        // automatic size: a generation run evaluates about n_slots * (n_sims + 1) positions per ply for ~20 plies, about a
+        // third of them distinct; 16 x the per-ply figure keeps the load factor of the linear-probing table under ~0.4
+        size_t want = c.eval_cache_entries > 0 ? (size_t)c.eval_cache_entries : (size_t)N * (size_t)(S + 1) * 16;
+        if (want < 1024) want = 1024;
+        if (want > ((size_t)1 << 26)) want = (size_t)1 << 26;       // entry index * 16 floats stays inside int32
+        int lg = 10;
+        while (((size_t)1 << lg) < want) ++lg;
+        e->ent_table = (size_t)1 << lg;
+        e->ent_shift = 64 - lg;
+        DEV_ALLOC(e->d_ent, e->ent_table + (size_t)N);
+        HIP_TRY(hipMemset(e->d_ent, 0, (e->ent_table + (size_t)N) * sizeof(EvalEnt)));
+    }
     { int rc = upload_exploration_tables(e); if (rc) return rc; }
     HIP_TRY(hipMemset(v.counters, 0, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc((void **)&e->h_res, sizeof(PlyResultDev), hipHostMallocDefault));
@@ -665,9 +673,9 @@ int azsp_set_evaluator(azsp_engine *e, int32_t kind, azsp_predict_fn fn, void *u
     if (kind < 0 || kind > AZSP_EVAL_HOST) return fail(AZSP_ERR_ARG, "unknown evaluator kind %d", kind);
     e->evaluator = kind;
     e->cb = fn;
-    e->epoch++;
     e->cb_user = user;
-    return 0;
+    ON_DEVICE(e->cfg.device);
+    return cache_clear(e);
 }
 
 int azsp_load_resnet(azsp_engine *e, const float *blob, size_t n_floats) {
@@ -680,8 +688,7 @@ int azsp_load_resnet(azsp_engine *e, const float *blob, size_t n_floats) {
     if (resnet_load(e->net, blob, n_floats, e->stream)) return fail(AZSP_ERR_HIP, "weight upload failed");
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->net_loaded = true;
-    e->epoch++;
-    return 0;
+    return cache_clear(e);
 }
 
 int azsp_sync(azsp_engine *e) {
@@ -780,7 +787,9 @@ int azsp_reset(azsp_engine *e) {
     launch_reset_slots(e->cfg.game, e->v, e->stream);
     e->searched = false;
     e->play_open = false;
-    int rc = sync_stream(e);
+    int rc = cache_clear(e);         // a position is evaluated at most once per generation run, never across runs
+    if (rc) return rc;
+    rc = sync_stream(e);
     if (rc) return rc;
     memset(e->h_res, 0, sizeof(PlyResultDev));      // the fetch/export calls check their ranges against this mirror
     return 0;
@@ -800,7 +809,6 @@ int azsp_set_search_options(azsp_engine *e, const azsp_search_options *o) {
         return fail(AZSP_ERR_ARG, "c_init / c_base must be numbers, c_base >= 0");
     ON_DEVICE(e->cfg.device);
     HIP_TRY(hipStreamSynchronize(e->stream));      // no search may be reading the tables
-    e->epoch++;
     e->v.sampling_plies = o->sampling_plies;
     e->v.noise_eps = o->noise_eps;
     e->v.noise_keep = 1.0 - o->noise_eps;
@@ -997,7 +1005,10 @@ int azsp_get_stats(azsp_engine *e, azsp_stats *out) {
     e->stats.path_nodes = e->h_counters[2];
     e->stats.rounds = e->rounds_host;
     e->stats.infer_union_ms = e->infer_union_ms;
-    e->stats.infer_boards = e->evaluator == AZSP_EVAL_RESNET ? e->h_counters[0] : 0;
+    e->stats.evals_executed = e->h_counters[4];
+    e->stats.infer_boards = e->evaluator == AZSP_EVAL_RESNET ? e->h_counters[4] : 0;
+    e->stats.infer_exec_flops_per_board = e->net ? resnet_exec_flops_per_board(e->net, e->cfg.game, e->last_infer_cap) : 0.0;
+    e->stats.eval_cache_entries = e->d_ent ? (uint64_t)e->ent_table : 0;
     *out = e->stats;
     return 0;
 }

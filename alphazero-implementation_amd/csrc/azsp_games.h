@@ -110,6 +110,16 @@ struct Connect4 {
         return 0;
     }
     static AZ_HD int bit_of(int r, int c) { return c * H1 + (ROWS - 1 - r); }
+    // Injective 49-bit key of a position in which every column is filled from the bottom without gaps (every position
+    // a game can reach): mine + occupied is, per 7-bit column of height h, a number in [2^h - 1, 2^(h+1) - 2] -- the
+    // ranges of different heights are disjoint, so h and with it `mine` can be read back.  Boards with a floating stone
+    // (callers may hand MCTS.run_batch anything) have no key: false.
+    static constexpr u64 BOTTOM = 1ull | (1ull << 7) | (1ull << 14) | (1ull << 21) | (1ull << 28) | (1ull << 35) | (1ull << 42);
+    static AZ_HD bool pos_key(const B &m, const B &t, u64 &key) {
+        const u64 occ = m.w[0] | t.w[0];
+        key = m.w[0] + occ;
+        return ((occ + BOTTOM) & occ) == 0 && (m.w[0] & t.w[0]) == 0;
+    }
 };
 
 // --------------------------------------------------------------------------------------------
@@ -135,6 +145,7 @@ struct Connect2 {
         return 0;
     }
     static AZ_HD int bit_of(int r, int c) { (void)r; return c * H1; }
+    static AZ_HD bool pos_key(const B &m, const B &t, u64 &key) { key = m.w[0] | (t.w[0] << 8); return true; }   // 4 cells: trivially injective
 };
 
 // --------------------------------------------------------------------------------------------
@@ -148,6 +159,7 @@ struct Gomoku9 {
     typedef Board<2> B;
 
     static AZ_HD int bit_of(int r, int c) { return r * H1 + c; }
+    static AZ_HD bool pos_key(const B &, const B &, u64 &key) { key = 0; return false; }     // 3^81 positions: no 64-bit key
     static AZ_HD bool legal(const B &m, const B &t, int a) {
         const int bit = bit_of(a / COLS, a % COLS);
         return !(board_bit(m, bit) | board_bit(t, bit));

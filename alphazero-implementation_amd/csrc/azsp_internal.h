@@ -32,13 +32,14 @@ struct alignas(16) BlockHead { double psum; int32_t flags; int32_t parent; };
 //   chunk 0  pending (leaf awaits evaluation), path_len (0 for a root expansion: no backup), leaf_node, n_blk
 //   chunk 1  root (node id of the current root; 0 unless the tree is being reused), root_kid (fresh root: 1 + block of its
 //            children, 0 = unexpanded), root_n / root_w (N and W of a fresh root)
-//   chunk 2  next_root (tree reuse: child chosen by k_finish, or -1), sims_done (FUSED rounds: simulations of this ply done)
+//   chunk 2  next_root (tree reuse: child chosen by k_finish, or -1), sims_done (FUSED rounds: simulations of this ply done),
+//            eval_ent (evaluation cache: the entry that holds, or will hold, the evaluator's row for the pending leaf)
 //   then     leaf position u64 mine[W], theirs[W]; then int32 path[MAX_PLIES + 2] (root .. leaf of the current descent)
 struct alignas(16) SlotHead {
     int32_t pending, path_len, leaf_node, n_blk;
     int32_t root, root_kid, root_n;
     float root_w;
-    int32_t next_root, sims_done, pad1, pad2;
+    int32_t next_root, sims_done, eval_ent, pad2;
 };
 template <class G>
 struct TreeGeo {
@@ -59,6 +60,29 @@ struct TreeGeo {
     static_assert(APL * LPG >= A + 1, "a block (children + header) must be covered by APL 16-byte loads per lane");
     static_assert(LPG > PATH_CHUNK, "the slot head and the leaf position come with the first 16-byte load of each lane");
 };
+
+// ------------------------------------------------------------------------------------------------
+// Evaluation cache (AZSP_FLAG_EVAL_CACHE): position -> (p, v), so that a position is evaluated ONCE per generation run.
+// ------------------------------------------------------------------------------------------------
+// The reference evaluates every leaf of every game in every round (monte_carlo_tree_search.py:154-157) and rebuilds
+// every tree every ply (:116-123); with no noise in the search, equal positions get equal (p, v) from a deterministic
+// evaluator, and the device evaluators are bitwise independent of the batch a position sits in (tested), so looking a
+// position's row up instead of recomputing it changes no bit of the search.
+// One array of 64-byte entries: [0, n_slots) one PRIVATE entry per slot (positions without a key, a full table, or a
+// position another slot group inserted during this very search), then a power-of-two open-addressing table (linear
+// probing, at most EVAL_PROBES steps).  An entry is claimed by ONE 64-bit compare-and-swap on its key word:
+//   bits 0..48  G::pos_key (injective, so a key match IS a position match -- no second compare, no lock)
+//   bits 49..51 slot group of the claiming launch      bits 52..63 epoch = number of the search (1..4095)
+// The claiming game ("owner") stores the position and puts the ENTRY on its group's leaf list; the inference kernel
+// reads the position from the entry and writes (p, v) into it; every game -- owner or not -- keeps the entry's index in
+// its slot record and reads the row from there when it expands the leaf in its group's next tree launch.  Ordering
+// needs nothing beyond streams: a row is read only (a) from an entry claimed by the reader's own slot group (its
+// inference launch sits between the claim and the read on the group's stream) or (b) from an entry claimed in an earlier
+// search (all group streams join the main stream at the end of every search).  A key claimed by ANOTHER group during the
+// current search is not usable yet: the game falls back to its private entry (a duplicate evaluation, same bits).
+struct alignas(64) EvalEnt { u64 key; u64 mine, theirs, pad; float row[8]; };   // row = p[0..A), value at [7]  (AP == 8 games)
+constexpr int EVAL_PROBES = 8;
+constexpr u64 EVAL_POS_MASK = (1ull << 49) - 1;
 
 // Device-resident state of one engine.
 struct View {
@@ -122,7 +146,13 @@ struct View {
     int32_t *out_values;                // [cap]
     uint8_t *out_actions;               // [cap] move played from the sample's position
     int64_t *totals;                    // [0] episodes, [1] samples, [2] ply index
-    // device-side counters: [0] evals, [1] terminal leaves, [2] path nodes, [3] rounds
+    // evaluation cache (nullptr = off: evaluator rows live in the slot records / eval_p as above)
+    EvalEnt *ent;
+    uint32_t ent_mask;      // table entries - 1 (the table starts at entry n_slots)
+    int32_t  ent_shift;     // 64 - log2(table entries)
+    int32_t  ent_epoch;     // number of this search, 1..4095
+    // device-side counters: [0] positions that needed the evaluator (the reference's evaluations), [1] terminal leaves,
+    // [2] path nodes, [3] rounds, [4] positions put on a leaf list = evaluations executed (== [0] without the cache)
     unsigned long long *counters;
 };
 
@@ -138,7 +168,7 @@ void tree_geometry(int game, int32_t *block_bytes, int32_t *slot_bytes, int32_t 
 void launch_root_prepare(int game, const View &v, hipStream_t s);
 void launch_select(int game, const View &v, hipStream_t s);
 void launch_compact(const View &v, hipStream_t s);
-void launch_eval_hash(int game, const View &v, uint64_t salt, hipStream_t s);
+void launch_eval_hash(int game, const View &v, uint64_t salt, hipStream_t s);      // (rows into the cache entries when v.ent)
 void launch_expand(int game, const View &v, hipStream_t s);
 void launch_expand_select(int game, const View &v, hipStream_t s);      // expand of round r-1 fused with select of round r
 void launch_leaf_cells(int game, const View &v, int8_t *dst, hipStream_t s);
@@ -167,13 +197,14 @@ size_t resnet_blob_floats(int game, int blocks, int channels);
 void resnet_forward(ResNetDev *, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot,
                     const int32_t *n_leaf, int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s);
 // (results of slot g: p at out_p + g * p_stride, value at out_v + g * v_stride -- strides in floats)
-// FUSED rounds (large-batch Connect-4 kernels of the fp32 network): one launch evaluates the listed leaves AND carries
-// those games on to their next leaf (azsp_tree_dev.h advance_game)
-bool resnet_has_fused(const ResNetDev *, int game, int max_leaves, bool small_only, int tab_lds);
+// FUSED rounds (one-board Connect-4 kernels of the fp32 network, up to 32 games): one launch evaluates the listed leaves
+// AND carries those games on to their next leaf (azsp_tree_dev.h advance_game)
+bool resnet_has_fused(const ResNetDev *, int game, int max_leaves, int tab_lds);
 void resnet_forward_fused(ResNetDev *, int game, const View &view, const u64 *leaf0, int board_stride, const int32_t *leaf_slot,
                           const int32_t *n_leaf, int32_t *next_list, int32_t *next_count, int32_t *zero_count, int max_leaves,
                           hipStream_t s);
 double resnet_flops_per_board(const ResNetDev *);
+double resnet_exec_flops_per_board(const ResNetDev *, int game, int max_leaves);   // matrix-pipe FLOP executed per board (variant of that capacity)
 // diagnostics: arm the stamped instantiation for this thread's next fp32 launch; read back its clock / span
 void resnet_trace_next();
 void resnet_trace_result(double *ghz, double *span_us);

@@ -307,18 +307,19 @@ struct Variant {
     int max_boards;                       // largest launch capacity this entry is chosen for
     void (*launch)(const FwdArgs &);
     int perm_offset;                      // which row-order table of ResNetDev::d_perm the kernel expects
+    int mt, pf, cw, rw;                   // the instantiation's row tiles per wave, prefetch form and wave grid (for the FLOP accounting)
 };
 static const Variant VARIANTS[] = {
-    {"c4_32_small", 0, 1, 768, fwd_c4_32_small, 0},   {"c4_32_big", 0, 1, INT_MAX, fwd_c4_32_big, 0},
-    {"c4_64_one", 0, 2, 320, fwd_c4_64_one, 0},       {"c4_64_mid", 0, 2, 768, fwd_c4_64_mid, 0},
-    {"c4_64_big", 0, 2, INT_MAX, fwd_c4_64_big, 256},
-    {"c4_96", 0, 3, INT_MAX, fwd_c4_96, 0},
-    {"c4_128_one", 0, 4, 512, fwd_c4_128_one, 0},     {"c4_128_mid", 0, 4, 768, fwd_c4_128_mid, 0},
-    {"c4_128_big", 0, 4, INT_MAX, fwd_c4_128_big, 256},
-    {"c4_192", 0, 6, INT_MAX, fwd_c4_192, 0},         {"c4_256", 0, 8, INT_MAX, fwd_c4_256, 0},
-    {"g9_32", 2, 1, INT_MAX, fwd_g9_32, 0},           {"g9_64", 2, 2, INT_MAX, fwd_g9_64, 0},
-    {"g9_96", 2, 3, INT_MAX, fwd_g9_96, 0},           {"g9_128", 2, 4, INT_MAX, fwd_g9_128, 0},
-    {"g9_192", 2, 6, INT_MAX, fwd_g9_192, 0},         {"g9_256", 2, 8, INT_MAX, fwd_g9_256, 0},
+    {"c4_32_small", 0, 1, 768, fwd_c4_32_small, 0, 1, 1, 1, 4},   {"c4_32_big", 0, 1, INT_MAX, fwd_c4_32_big, 0, 2, 0, 1, 4},
+    {"c4_64_one", 0, 2, 320, fwd_c4_64_one, 0, 1, 0, 2, 2},       {"c4_64_mid", 0, 2, 768, fwd_c4_64_mid, 0, 2, 0, 2, 2},
+    {"c4_64_big", 0, 2, INT_MAX, fwd_c4_64_big, 256, 4, 0, 2, 2},
+    {"c4_96", 0, 3, INT_MAX, fwd_c4_96, 0, 1, 1, 1, 4},
+    {"c4_128_one", 0, 4, 512, fwd_c4_128_one, 0, 1, 0, 4, 2},     {"c4_128_mid", 0, 4, 768, fwd_c4_128_mid, 0, 2, 0, 4, 2},
+    {"c4_128_big", 0, 4, INT_MAX, fwd_c4_128_big, 256, 4, 0, 4, 2},
+    {"c4_192", 0, 6, INT_MAX, fwd_c4_192, 0, 2, 1, 3, 2},         {"c4_256", 0, 8, INT_MAX, fwd_c4_256, 0, 2, 1, 4, 2},
+    {"g9_32", 2, 1, INT_MAX, fwd_g9_32, 0, 2, 0, 1, 4},           {"g9_64", 2, 2, INT_MAX, fwd_g9_64, 0, 2, 0, 1, 4},
+    {"g9_96", 2, 3, INT_MAX, fwd_g9_96, 0, 3, 0, 3, 1},           {"g9_128", 2, 4, INT_MAX, fwd_g9_128, 0, 3, 0, 4, 1},
+    {"g9_192", 2, 6, INT_MAX, fwd_g9_192, 0, 3, 0, 6, 1},         {"g9_256", 2, 8, INT_MAX, fwd_g9_256, 0, 3, 0, 8, 1},
 };
 
 static const Variant *pick_variant(const ResNetDev *n, int game, int max_leaves) {
@@ -326,6 +327,29 @@ static const Variant *pick_variant(const ResNetDev *n, int game, int max_leaves)
     for (const Variant &v : VARIANTS)
         if (v.game == game && v.nt == n->g.NT && max_leaves <= v.max_boards) return &v;
     return nullptr;
+}
+
+// Matrix-pipe FLOP the variant chosen for launches of capacity max_leaves executes per board slot of a full workgroup
+// (bench.py's roofline numerator): the tower's GEMM rows include the padding rows of the workgroup's tile (6 boards =
+// 252 of 256 rows, one board = 42 of 64) and the padded channels, the tap-skipping row order drops 3 of 18 tile-taps
+// per 3x3 convolution (exact zeros), the 9x9 one-board kernels compute exactly their 81 cells (80 on MFMAs, the corner
+// on the vector ALU); stem and heads are counted as in the algorithmic figure.  The split-fp16 kernel (always 6 boards,
+// tap skipping) issues three fp16 MFMAs per fp32 multiply-add.
+double resnet_exec_flops_per_board(const ResNetDev *n, int game, int max_leaves) {
+    if (!n) return 0.0;
+    const NetGeom &g = n->g;
+    const double C = g.C, cells = g.cells;
+    const double tower = 2.0 * cells * 2.0 * g.blocks * C * C * 9;
+    const double rest = n->flops_per_board - tower;
+    const double pad_ch = ((double)g.Cp / C) * ((double)g.Cp / C);
+    if (n->f16) return 3.0 * (tower * (256.0 / (6.0 * cells)) * (5.0 / 6.0) * pad_ch + rest);
+    const Variant *v = pick_variant(n, game, max_leaves);
+    if (!v) return 0.0;
+    const int wg_rows = v->rw * 32 * v->mt, tb = wg_rows / g.cells;
+    const bool sk = game == 0 && v->pf == 0 && ((v->mt == 2 && v->rw == 4) || (v->mt == 4 && v->rw == 2 && v->cw == v->nt));
+    const bool tile16 = game == 2 && v->pf == 0 && v->cw == v->nt && v->rw == 1 && v->mt == 3 && v->nt >= 3;
+    const double rows = tile16 ? cells : (double)wg_rows / tb;
+    return tower * (rows / cells) * (sk ? 5.0 / 6.0 : 1.0) * pad_ch + rest;
 }
 
 // AZSP_RESNET_VARIANT, resolved once per network
@@ -338,29 +362,22 @@ int resnet_forced_variant(int game, int nt) {
     return -1;
 }
 
-// FUSED rounds exist for the Connect-4 kernels of the exact-fp32 network at 64 / 128 channels: the one-board workgroups
-// of small batches (small = true) and the six-board ones of large batches
-static void (*fused_launcher(const ResNetDev *n, int game, int max_leaves, bool *small))(const FwdArgs &) {
-    if (small) *small = false;
+// FUSED rounds exist for the one-board Connect-4 kernels of the exact-fp32 network at 64 / 128 channels (the large-batch
+// forms measured slower than two launches per round and were retired after round 2)
+static void (*fused_launcher(const ResNetDev *n, int game, int max_leaves))(const FwdArgs &) {
     if (n->f16 || game != 0 || n->forced_variant >= 0) return nullptr;
     const Variant *v = pick_variant(n, game, max_leaves);
-    if (v && v->launch == fwd_c4_64_big) return fwd_c4_64_big_fused;
-    if (v && v->launch == fwd_c4_128_big) return fwd_c4_128_big_fused;
-    if (small) *small = true;
     if (v && v->launch == fwd_c4_64_one) return fwd_c4_64_one_fused;
     if (v && v->launch == fwd_c4_128_one) return fwd_c4_128_one_fused;
     return nullptr;
 }
-// small_only: the caller wants FUSED rounds only where they are the faster form (launch-latency-bound small batches);
 // tab_lds: exploration-table entries the tree step stages in LDS over the one-board kernel's dead activation rows
-bool resnet_has_fused(const ResNetDev *n, int game, int max_leaves, bool small_only, int tab_lds) {
-    if (!n) return false;
-    bool small = false;
-    if (!fused_launcher(n, game, max_leaves, &small)) return false;
-    if (small && tab_lds > 1024) return false;              // 2 * 1024 + 480 floats of tree scratch fit 65 x 68 activation floats
+bool resnet_has_fused(const ResNetDev *n, int game, int max_leaves, int tab_lds) {
+    if (!n || !fused_launcher(n, game, max_leaves)) return false;
+    if (tab_lds > 1024) return false;              // 2 * 1024 + 480 floats of tree scratch fit 65 x 68 activation floats
     // measured (one MI355X, 64 channels, 100 simulations): 106.6 -> 101.0 us per round with one game, 118.3 -> 114.2 with 8,
-    // 117.9 -> 121.2 with 100 (the tree tail then delays other workgroups' launch slots): the default only for a few games
-    return small_only ? small && max_leaves <= 32 : true;
+    // 117.9 -> 121.2 with 100 (the tree tail then delays other workgroups' launch slots): only for a few games
+    return max_leaves <= 32;
 }
 
 static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
@@ -407,7 +424,7 @@ static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_str
     P.conv_w4 = n->has_w4 ? d + n->o_conv_w4 : nullptr;
     a.mine = leaf0; a.theirs = leaf0 + n->g_words; a.bstride = board_stride; a.leaf_slot = leaf_slot; a.n_leaf = n_leaf; a.max_leaves = max_leaves;
     a.out_p = out_p; a.out_v = out_v; a.p_stride = p_stride; a.v_stride = v_stride; a.s = s;
-    if (fused) fused_launcher(n, game, max_leaves, nullptr)(a);
+    if (fused) fused_launcher(n, game, max_leaves)(a);
     else v->launch(a);
 }
 

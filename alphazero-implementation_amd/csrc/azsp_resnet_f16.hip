@@ -779,6 +779,7 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
                     break;
                 }
             }
+#ifdef AZSP_DIAG_BUILD   /* build.py --diag only (csrc/libazsp_diag.so): never part of the product library */
             static const int abl = [] { const char *e = getenv("AZSP_F16_ABLATE"); return e ? atoi(e) : 0; }();
             if (abl) {   // timing-only diagnostic builds (wrong results): 1 = no weight streaming, 2 = no LDS fragment traffic, 4 = no activation stores
                 if (abl == 1) launch16<2, 2, 1>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s);
@@ -787,6 +788,7 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
                 else launch16<2, 2, 4>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s);
                 break;
             }
+#endif
             if (wr_env == 4 || (!wr_env && max_leaves <= 768)) L16(2, 4); else L16(2, 2);   // small batch: more waves per board
             break;
         }

@@ -1287,8 +1287,6 @@ static void launch_forward(const FwdArgs &a) {
 // One function per compiled kernel variant (azsp_resnet_k*.hip); the table that picks among them is in azsp_resnet.hip.
 void fwd_c4_64_big(const FwdArgs &);      // Connect-4, 64 ch, 6 boards / workgroup, 2 x 2 waves, static tower (+ traced form)
 void fwd_c4_128_big(const FwdArgs &);     // Connect-4, 128 ch, 6 boards / workgroup, 2 x 4 waves, static tower
-void fwd_c4_64_big_fused(const FwdArgs &);    // the same two with the tree step of the evaluated games fused in (FUSED rounds)
-void fwd_c4_128_big_fused(const FwdArgs &);
 void fwd_c4_64_one_fused(const FwdArgs &);    // the one-board kernels of small batches with the tree step fused in
 void fwd_c4_128_one_fused(const FwdArgs &);
 void fwd_c4_32_small(const FwdArgs &);    // Connect-4, 32 ch, 3 boards / workgroup, double-buffered weight stream

@@ -100,8 +100,19 @@ __global__ void k_root_prepare(View v) {
     else { h->path_len = 1; path[0] = root; }      // search.py:72-91: expanding the root IS simulation 1
     h->leaf_node = root;
     h->sims_done = 0;
-    slot_store_leaf<G>(v, g, board_load<G::W>(v.cur_mine, g), board_load<G::W>(v.cur_theirs, g));
+    const typename G::B rm = board_load<G::W>(v.cur_mine, g), rt = board_load<G::W>(v.cur_theirs, g);
+    slot_store_leaf<G>(v, g, rm, rt);
     h->pending = 1;
+    if constexpr (G::W == 1) {
+        // evaluation cache: the root joins the group's leaf list here (as the entry to evaluate, if this game claimed
+        // one) instead of through k_compact; the host zeroed the list's counter before this launch
+        if (v.ent != nullptr) {
+            bool owner;
+            const int id = ent_claim<G>(v, g, rm, rt, owner);
+            h->eval_ent = id;
+            append_leaves(v, true, owner, id, v.leaf_slot, v.nl);
+        }
+    }
 }
 
 // dynamic LDS of the tree kernels: [GPW games][D] path staging, then the exploration table(s)
@@ -116,7 +127,14 @@ static inline size_t tree_lds_bytes(const View &v) {
 
 // the evaluator's output for game g as expand_game wants it: this lane's actions and the value
 template <class G>
-__device__ __forceinline__ float eval_rows(const View &v, int g, int lane, bool live, float (&p32)[G::APL]) {
+__device__ __forceinline__ float eval_rows(const View &v, int g, int lane, bool live, const SlotRegs<G> &st, float (&p32)[G::APL]) {
+    if constexpr (G::W == 1 && G::APL == 1) {
+        if (v.ent != nullptr) {                               // evaluation cache: the row sits in the entry the slot points at
+            const float *row = v.ent[live ? st.eval_ent : 0].row;
+            p32[0] = (live && lane < G::A) ? row[lane] : 0.0f;
+            return live ? row[7] : 0.0f;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < G::APL; ++k) {
         const int a = lane + k * G::LPG;
@@ -138,7 +156,9 @@ __global__ __launch_bounds__(64) void k_select(View v) {
     SlotRegs<G> st;
     slot_load<G>(v, g, lane, live, st);
     __syncthreads();
-    select_game<G, R>(v, g, lane, grp, live, st, s_path, tb);
+    int leaf_id;
+    bool leaf_add;                     // (the slot-ordered four-launch rounds run without the evaluation cache: v.ent == nullptr)
+    select_game<G, R>(v, g, lane, grp, live, st, s_path, tb, leaf_id, leaf_add);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -165,6 +185,7 @@ __global__ __launch_bounds__(1024) void k_compact(View v) {
     if (t == 1023) {
         v.nl[0] = s_sum[1023];
         atomicAdd(&v.counters[0], (unsigned long long)s_sum[1023]);
+        atomicAdd(&v.counters[4], (unsigned long long)s_sum[1023]);
     }
 }
 
@@ -177,6 +198,18 @@ __global__ void k_eval_hash(View v, uint64_t salt) {
     if (j >= v.nl[0]) return;
     const int g = v.leaf_slot[v.lo + j];
     typename G::B m, t;
+    if constexpr (G::W == 1) {
+        if (v.ent != nullptr) {            // evaluation cache: the list holds entries; position from and row into the entry
+            EvalEnt *e = &v.ent[g];
+            m.w[0] = e->mine;
+            t.w[0] = e->theirs;
+            float row[G::AP];
+            const float val = hash_eval<G>(m, t, salt, row);
+            for (int a = 0; a < G::AP; ++a) e->row[a] = a < G::A ? row[a] : 0.0f;
+            e->row[7] = val;
+            return;
+        }
+    }
     leaf_boards<G>(v, g, m, t);
     float *p = v.eval_p + (size_t)g * v.eval_pstride;
     const float val = hash_eval<G>(m, t, salt, p);
@@ -207,7 +240,7 @@ __global__ __launch_bounds__(64) void k_expand(View v) {
     slot_load<G>(v, g, lane, in, st);
     const bool live = in && st.pending != 0;
     float p32[G::APL];
-    const float vleaf = eval_rows<G>(v, g, lane, live, p32);
+    const float vleaf = eval_rows<G>(v, g, lane, live, st, p32);
     expand_game<G, R>(v, g, lane, grp, live, st, p32, vleaf, s_pa);
     if (live && lane == 0) slot_store_head<G>(v, g, st);
 }
@@ -237,7 +270,7 @@ __global__ __launch_bounds__(64) void k_expand_select(View v) {
     slot_load<G>(v, g, lane, in, st);
     const bool pend = in && st.pending != 0;
     float p32[G::APL];
-    const float vleaf = eval_rows<G>(v, g, lane, pend, p32);
+    const float vleaf = eval_rows<G>(v, g, lane, pend, st, p32);
     expand_game<G, R>(v, g, lane, grp, pend, st, p32, vleaf, s_pa);
     if (pend && lane == 0) slot_store_head<G>(v, g, st);
     __syncthreads();
@@ -245,8 +278,11 @@ __global__ __launch_bounds__(64) void k_expand_select(View v) {
     // inside this launch, so the stores above only have to be ordered before this wave's own loads: a workgroup-scope
     // fence (s_waitcnt) -- an agent-scope fence would write back and invalidate the XCD's L2 from every wave.
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    const int term = select_game<G, R>(v, g, lane, grp, in, st, s_path, tb);
-    append_leaves(v, in && term == TERM_NONE && lane == 0, g, v.leaf_slot, v.nl);
+    int leaf_id;
+    bool leaf_add;
+    const int term = select_game<G, R>(v, g, lane, grp, in, st, s_path, tb, leaf_id, leaf_add);
+    const bool need = in && term == TERM_NONE && lane == 0;
+    append_leaves(v, need, need && leaf_add, leaf_id, v.leaf_slot, v.nl);
 }
 
 // listed leaf positions as int8 cells, for the host evaluator

@@ -54,6 +54,7 @@ template <class G>
 struct SlotRegs {
     int pending, path_len, leaf_node, n_blk, root, root_kid, root_n, next_root;
     int sims_done;                              // simulations of this ply finished so far (FUSED rounds)
+    int eval_ent;                               // evaluation cache: entry holding the pending leaf's row
     float root_w;
     typename G::B lm, lt;                       // leaf position
     int4 sc[TreeGeo<G>::CPL];
@@ -85,6 +86,7 @@ __device__ __forceinline__ void slot_load(const View &v, int g, int lane, bool l
     st.root = c1.x; st.root_kid = c1.y; st.root_n = c1.z; st.root_w = __int_as_float(c1.w);
     st.next_root = c2.x;
     st.sims_done = c2.y;
+    st.eval_ent = c2.z;
     if constexpr (G::W == 1) {
         const int4 b = slot_chunk_bcast<G>(st, T::LEAF_CHUNK);
         st.lm.w[0] = (u64)(uint32_t)b.x | ((u64)(uint32_t)b.y << 32);
@@ -109,7 +111,7 @@ __device__ __forceinline__ void slot_store_head(const View &v, int g, const Slot
     int4 *dst = reinterpret_cast<int4 *>(slot_ptr(v, g));
     dst[0] = make_int4(st.pending, st.path_len, st.leaf_node, st.n_blk);
     dst[1] = make_int4(st.root, st.root_kid, st.root_n, __float_as_int(st.root_w));
-    dst[2] = make_int4(st.next_root, st.sims_done, 0, 0);
+    dst[2] = make_int4(st.next_root, st.sims_done, st.eval_ent, 0);
 }
 template <class G>
 __device__ __forceinline__ void slot_store_leaf(const View &v, int g, const typename G::B &m, const typename G::B &t) {
@@ -139,6 +141,39 @@ __device__ __forceinline__ void leaf_boards(const View &v, int g, typename G::B 
     for (int i = 0; i < G::W; ++i) { m.w[i] = src[i]; t.w[i] = src[G::W + i]; }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// evaluation cache (layout and protocol: azsp_internal.h)
+// ------------------------------------------------------------------------------------------------
+// Finds or claims the entry of position (m, t) for game g of the launch's slot group.  Returns the entry index and
+// whether the caller must put it on the leaf list (it claimed a table entry, or fell back to its private one).
+template <class G>
+__device__ __forceinline__ int ent_claim(const View &v, int g, const typename G::B &m, const typename G::B &t, bool &owner) {
+    u64 pk = 0;
+    int id = g;                                                // the slot's private entry
+    owner = true;
+    if (G::pos_key(m, t, pk)) {
+        const u64 word = pk | ((u64)v.grp << 49) | ((u64)v.ent_epoch << 52);
+        uint32_t h = (uint32_t)((pk * 0x9E3779B97F4A7C15ull) >> v.ent_shift);
+        for (int probe = 0; probe < EVAL_PROBES; ++probe, h = (h + 1) & v.ent_mask) {
+            unsigned long long *kp = reinterpret_cast<unsigned long long *>(&v.ent[(size_t)v.n_slots + h].key);
+            const u64 old = atomicCAS(kp, 0ull, (unsigned long long)word);
+            if (old == 0) { id = v.n_slots + (int)h; break; }                   // claimed
+            if ((old & EVAL_POS_MASK) == pk) {
+                // the same position: usable if this group claimed it (its inference launch precedes our next read on the
+                // group's stream) or an earlier search did (all streams joined since); otherwise evaluate privately
+                if ((int)((old >> 49) & 7) == v.grp || (int)(old >> 52) != v.ent_epoch) { id = v.n_slots + (int)h; owner = false; }
+                break;
+            }
+        }
+    }
+    if (owner) {
+        EvalEnt *e = &v.ent[id];
+        e->mine = m.w[0];
+        e->theirs = t.w[0];
+    }
+    return id;
+}
 
 // ------------------------------------------------------------------------------------------------
 // expansion + backup of an evaluated leaf (Node.expand :80-90, backpropagate :214-223, mask / renormalise :119-121)
@@ -259,9 +294,13 @@ __device__ __forceinline__ void expand_game(const View &v, int g, int lane, int 
 // APPEND: the non-terminal leaves are appended to the group's leaf list here (one atomic per wavefront; the order of
 // the list does not matter to the device evaluators, whose outputs do not depend on a position's place in the batch)
 // instead of by the stable k_compact pass that the host-callback evaluator needs.
+// leaf_id / leaf_add (meaningful on lane 0 of a game whose descent ended on a non-terminal leaf): what goes on the leaf
+// list -- the slot itself, or with the evaluation cache the entry to evaluate, and only if this game claimed it
 template <class G, int R>
 __device__ __forceinline__ int select_game(const View &v, int g, int lane, int grp, bool live, SlotRegs<G> &st, int *s_path,
-                                            const Tabs &tb) {
+                                            const Tabs &tb, int &leaf_id, bool &leaf_add) {
+    leaf_id = g;
+    leaf_add = true;
     using WT = typename std::conditional<R == 0, float, double>::type;
     using T = TreeGeo<G>;
     constexpr int A = G::A, LPG = G::LPG, APL = G::APL;
@@ -432,9 +471,16 @@ __device__ __forceinline__ int select_game(const View &v, int g, int lane, int g
             h->pending = 1;
             h->path_len = L;
             h->leaf_node = node;
+            if constexpr (G::W == 1) {
+                if (v.ent != nullptr) {
+                    leaf_id = ent_claim<G>(v, g, bm, bt, leaf_add);
+                    h->eval_ent = leaf_id;
+                }
+            }
             slot_store_leaf<G>(v, g, bm, bt);
             atomicAdd(&v.counters[2], (unsigned long long)L);
         }
+        if constexpr (G::W == 1) st.eval_ent = __shfl(leaf_id, 0, LPG);
     }
     return term;
 }
@@ -442,19 +488,24 @@ __device__ __forceinline__ int select_game(const View &v, int g, int lane, int g
 // The non-terminal leaves found by a wave join a leaf list: one atomic per wavefront (the order of the list does not
 // matter to the device evaluators, whose outputs do not depend on a position's place in the batch, and results come
 // back by slot).  `list` is indexed from the group's first slot `lo`; `count` is the list's length counter.
-__device__ __forceinline__ void append_leaves(const View &v, bool mine_to_add, int g, int32_t *list, int32_t *count) {
-    const unsigned long long bal = __ballot(mine_to_add);
+// `need`: this lane's game found a position that needs the evaluator (counted as one of the reference's evaluations);
+// `add` (implies need): its list entry `id` -- the slot, or with the evaluation cache the entry this game claimed --
+// joins the list (counted as an evaluation executed).
+__device__ __forceinline__ void append_leaves(const View &v, bool need, bool add, int id, int32_t *list, int32_t *count) {
+    const unsigned long long bal_need = __ballot(need);
+    const unsigned long long bal = __ballot(add);
     const int cnt = __popcll(bal);
+    const int wl = threadIdx.x & 63;
+    if (bal_need != 0 && wl == __ffsll((long long)bal_need) - 1) atomicAdd(&v.counters[0], (unsigned long long)__popcll(bal_need));
     int base_j = 0;
     if (cnt > 0) {
         const int leader = __ffsll((long long)bal) - 1;
-        const int wl = threadIdx.x & 63;
         if (wl == leader) {
             base_j = atomicAdd(count, cnt);
-            atomicAdd(&v.counters[0], (unsigned long long)cnt);
+            atomicAdd(&v.counters[4], (unsigned long long)cnt);
         }
         base_j = __shfl(base_j, leader, 64);
-        if (mine_to_add) list[v.lo + base_j + __popcll(bal & ((1ull << wl) - 1ull))] = g;
+        if (add) list[v.lo + base_j + __popcll(bal & ((1ull << wl) - 1ull))] = id;
     }
 }
 
@@ -476,7 +527,9 @@ __device__ __forceinline__ void advance_game(const View &v, int g, int lane, int
     bool found = false;
     while (__any(again)) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // this wave's stores before its own next loads
-        const int term = select_game<G, R>(v, g, lane, grp, again, st, s_path, tb);
+        int leaf_id;
+        bool leaf_add;
+        const int term = select_game<G, R>(v, g, lane, grp, again, st, s_path, tb, leaf_id, leaf_add);     // (FUSED rounds run without the evaluation cache)
         if (again) {
             if (term != TERM_NONE) {
                 st.sims_done += 1;
@@ -489,7 +542,7 @@ __device__ __forceinline__ void advance_game(const View &v, int g, int lane, int
         }
         wave_lds_sync();                                             // the path staging area is reused by the next descent
     }
-    append_leaves(v, found && lane == 0, g, next_list, next_count);
+    append_leaves(v, found && lane == 0, found && lane == 0, g, next_list, next_count);
 }
 }  // namespace azsp
 

@@ -4,6 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no launcher environment (WORLD_SIZE unset) makes bench.py its own launcher: before
+anything touches a GPU it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child
+process (N fresh rank processes), relays rank 0's JSON line and exits with the child's code; it refuses to run
+when fewer than N GPUs are visible.  `--gpus` never silently measures fewer GPUs than it names.
+
 A *step* is one complete `EpisodeGenerator.generate_episodes` call of the workload: `--slots`
 concurrent Connect-4 games per GPU (default 4096 = BASELINE.json configs[1]), `--sims` MCTS
 simulations per move, random-weight ResNet(`--blocks`, `--channels`), run until `slots` episodes have
@@ -15,6 +20,9 @@ The headline (`value`, `roofline`) is measured with the inference kernel in exac
 with the split-fp16 inference kernel (fp32 operands carried as two fp16 numbers, fp32 accumulate; same
 accuracy bound in the tests) and reported under `"f16x2"`; `--precision f16x2` makes that the headline.
 
+After those, the same workload is measured with the evaluation cache on (`"eval_cache"`: every position evaluated
+at most once per generate_episodes call -- identical episodes, tested; NOT the headline until a verdict accepts it).
+
 The JSON line carries the MFMA roofline of the dominant kernel (timed with HIP events on the engine's
 own streams inside the timed region) and a CPU baseline: the oracle's pure-Python/torch-CPU port of the
 reference path timed on this box's host cores (rank 0, N=1 only)."""
@@ -23,6 +31,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -98,6 +108,49 @@ def pmc_traffic(kernel: str):
     return d.get(kernel, {}).get("bytes_per_launch")
 
 
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """`bench.py --gpus n` started without a launcher: this process has not touched a GPU yet (device_count() does not
+    initialise one), so it may start the n rank processes itself -- fresh children through torch.distributed.run, one
+    per GPU -- and hand their exit code on.  Rank 0's JSON line goes straight to our stdout."""
+    backend = os.environ.get("AZSP_BENCH_BACKEND", "nccl")
+    rehearse = os.environ.get("AZSP_BENCH_REHEARSE") == "1"
+    if backend == "nccl" and not rehearse:
+        n_dev = torch.cuda.device_count()
+        if n_dev < n:
+            print(f"bench.py: --gpus {n} but only {n_dev} GPU(s) visible: refusing to report a {n}-GPU number measured on fewer "
+                  f"(AZSP_BENCH_BACKEND=gloo rehearses the N-rank path on fewer GPUs)", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["AZSP_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+class RehearsalGenerator:
+    """AZSP_BENCH_REHEARSE=1: no engine, no GPU -- each step fabricates packed records so that the launcher, the
+    rendezvous, the timing fences, the variable-length all-gather and combine_ranks can be run end to end on a CPU
+    box (tests/test_distributed_cpu.py).  The line it produces says so and carries no throughput."""
+
+    def __init__(self, slots: int, rank: int):
+        self.slots, self.rank = slots, rank
+
+    def step(self, seed: int, dist, world: int, coll_dev):
+        from azsp.distributed import all_gather_variable, pack_records
+        rng = np.random.RandomState(seed)
+        n = self.slots * 3 + self.rank
+        counts = rng.randint(0, 30, size=(n, 7)) + 1
+        rec = torch.from_numpy(pack_records(rng.randint(-1, 2, size=(n, 42)).astype(np.int8), counts / counts.sum(axis=1, keepdims=True),
+                                            rng.randint(-1, 2, size=n).astype(np.int32)))
+        tg = time.perf_counter()
+        gathered = all_gather_variable(rec, dist, world) if dist is not None else None
+        return self.slots, n, gathered, time.perf_counter() - tg
+
+
 def combine_ranks(dist, world: int, coll_dev, dt: float, episodes: int, samples: int, gathered_records: int,
                   gather_s: float) -> dict:
     """What the ranks exchange after the timed region (also exercised by the 2-rank gloo test): the step time is the
@@ -164,27 +217,40 @@ def main() -> None:
     ap.add_argument("--single", action="store_true", help="measure only --precision")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the in-kernel clock measurement after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eval-cache", action="store_true", help="skip the evaluation-cache measurements")
+    ap.add_argument("--eval-cache-headline", action="store_true", help="diagnostics: make the evaluation-cache run the top-level line")
     ap.add_argument("--game", choices=["connect4", "gomoku9"], default="connect4",
                     help="gomoku9 = BASELINE.json configs[4]'s game (not a headline config; fp32 only, no CPU baseline)")
     args = ap.parse_args()
     if args.game == "gomoku9":
         args.single, args.no_cpu_baseline, args.precision = True, True, "f32"
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: become one (nothing in this process has initialised a GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); start it as "
+                         f"`python bench.py --gpus {args.gpus}` (bench.py launches its own ranks) or "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}`")
+    rehearse = os.environ.get("AZSP_BENCH_REHEARSE") == "1"
+    if rehearse:
+        args.single, args.no_cpu_baseline, args.no_clock_probe, args.no_eval_cache = True, True, True, True
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the self-play engine has no CPU path")
     # one process per GPU; AZSP_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks
-    backend = os.environ.get("AZSP_BENCH_BACKEND", "nccl")
-    n_dev = torch.cuda.device_count()
+    backend = "gloo" if rehearse else os.environ.get("AZSP_BENCH_BACKEND", "nccl")
+    n_dev = 0 if rehearse else torch.cuda.device_count()
     if backend == "nccl" and world > n_dev:
         raise SystemExit(f"bench.py: {world} ranks but only {n_dev} GPU(s) visible: one process per GPU over RCCL needs one device "
                          f"per rank (AZSP_BENCH_BACKEND=gloo rehearses the collectives with several ranks on fewer GPUs)")
-    local_rank %= n_dev                        # (only the gloo rehearsal mode can have more ranks than devices)
-    torch.cuda.set_device(local_rank)
+    if not rehearse:
+        local_rank %= n_dev                    # (only the gloo rehearsal mode can have more ranks than devices)
+        torch.cuda.set_device(local_rank)
     coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1 or os.environ.get("AZSP_BENCH_FORCE_DIST") == "1":   # the latter: 1-rank rehearsal of the RCCL calls
@@ -211,13 +277,20 @@ def main() -> None:
     def fence():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not rehearse:
+            torch.cuda.synchronize()
 
-    def measure(precision: str) -> dict:
-        gen = azsp.EpisodeGenerator(game=game_cls(), config=cfg, device=local_rank, timing=True,
-                                    n_groups=args.groups, f16_split=precision == "f16x2")
+    def measure(precision: str, eval_cache: bool = False) -> dict:
+        if rehearse:
+            reh = RehearsalGenerator(args.slots, rank)
+            gen = None
+        else:
+            gen = azsp.EpisodeGenerator(game=game_cls(), config=cfg, device=local_rank, timing=True, n_groups=args.groups,
+                                        f16_split=precision == "f16x2", eval_cache=eval_cache)
 
         def step(seed: int):
+            if rehearse:
+                return reh.step(seed, dist, world, coll_dev)
             np.random.seed(seed)               # independent replica per rank (SURVEY 8e mode B)
             eps = list(gen.generate_episodes(net))
             tg = time.perf_counter()
@@ -228,17 +301,15 @@ def main() -> None:
 
         for w in range(args.warmup):
             step(1000 * (w + 1) + rank)
-        eng = gen.engine_for(net)
-        eng.reset_stats()
+        eng = None if rehearse else gen.engine_for(net)
+        if eng is not None:
+            eng.reset_stats()
         fence()
         t0 = time.perf_counter()
         episodes = samples = gathered_records = 0
         gather_s = 0.0
-        t_own = 0.0
         for k in range(args.steps):
-            ts = time.perf_counter()
             e, s, g, tg = step(10 * k + rank)
-            t_own += time.perf_counter() - ts
             episodes += e
             samples += s
             gather_s += tg
@@ -246,10 +317,15 @@ def main() -> None:
                 gathered_records += sum(int(x.shape[0]) for x in g)
         fence()
         dt = time.perf_counter() - t0
-        st = eng.stats()
+        st = eng.stats() if eng is not None else None
         # gathered_records counts every rank's records as seen here; samples is this rank's own until combined
         comb = combine_ranks(dist, world, coll_dev, dt, episodes, samples, gathered_records, gather_s)
         dt, episodes, samples = comb["dt"], comb["episodes"], comb["samples"]
+        ranks = {"ms_per_step": [1e3 * x / max(args.steps, 1) for x in comb["per_rank_s"]],
+                 "allgather_ms_per_step": [1e3 * x / max(args.steps, 1) for x in comb["allgather_s"]]}
+        if rehearse:
+            return {"value": 0.0, "unit": "episodes/s", "ms_per_step": 1e3 * dt / max(args.steps, 1), "dtype": "none (rehearsal)",
+                    "episodes": episodes, "samples": samples, "ranks": ranks, "roofline": None, "tree": None}
         eng.close()
         launches = max(int(st["infer_launches"]), 1)
         avg_ms = st["infer_ms"] / launches
@@ -257,26 +333,36 @@ def main() -> None:
         # union of the launch intervals: flops per launch / (average launch duration / overlap factor).
         union_ms = st["infer_union_ms"] if st["infer_union_ms"] > 0 else st["infer_ms"]
         overlap = st["infer_ms"] / union_ms if union_ms > 0 else 1.0
-        achieved = fpb * st["infer_boards"] / (union_ms * 1e-3) / 1e12 if union_ms > 0 else 0.0
         peak = PEAK_TFLOPS[precision]
+        boards = st["infer_boards"]                  # positions the kernel evaluated (== evals unless the evaluation cache is on)
+        # EXECUTED matrix-pipe FLOP per board of the kernel variant in use (libazsp: padding rows of the workgroup tile
+        # included, statically skipped off-board taps excluded, x 3 for f16x2's hi*hi + hi*lo + lo*hi); a full last
+        # workgroup is assumed for every launch (214 workgroups per launch at the headline: < 0.5 %)
+        efpb = st["infer_exec_flops_per_board"]
+        tf = lambda flop, ms: flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0      # noqa: E731
+        achieved = tf(efpb * boards, union_ms)
+        algorithmic = tf(fpb * boards, union_ms)
         return {
             "value": episodes / dt, "unit": "episodes/s", "ms_per_step": 1e3 * dt / max(args.steps, 1), "dtype": DTYPE[precision],
-            "episodes": episodes, "samples": samples,
-            "ranks": {"ms_per_step": [1e3 * x / max(args.steps, 1) for x in comb["per_rank_s"]],
-                      "allgather_ms_per_step": [1e3 * x / max(args.steps, 1) for x in comb["allgather_s"]]},
+            "episodes": episodes, "samples": samples, "ranks": ranks,
+            "evals": int(st["evals"]), "evals_executed": int(st["evals_executed"]),
+            **({"eval_cache": {"entries": int(st["eval_cache_entries"]),
+                               "hit_rate": 1.0 - st["evals_executed"] / max(st["evals"], 1),
+                               "reference_evals_per_executed": st["evals"] / max(st["evals_executed"], 1)}} if eval_cache else {}),
+            # frac = EXECUTED matrix FLOP / time with >= 1 inference launch running / peak: <= 1 by construction.
+            # algorithmic_* = the same with SURVEY 8d's dense FLOP count per evaluated board (the kernel skips
+            # exact-zero taps, so this one can exceed 1); frac_over_wall = executed FLOP / whole step time / peak.
             "roofline": {"bound": "mfma", "kernel": KERNEL[precision], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": pmc_traffic(KERNEL[precision]), "flops_per_board": fpb,
-                         "boards_per_launch": st["infer_boards"] / launches, "avg_launch_ms": avg_ms, "launches": launches,
+                         "frac": achieved / peak, "traffic": pmc_traffic(KERNEL[precision]),
+                         "executed_flops_per_board": efpb, "flops_per_board": fpb,
+                         "algorithmic_achieved": algorithmic, "algorithmic_frac": algorithmic / peak,
+                         "frac_over_wall": tf(efpb * boards, dt * 1e3) / peak,
+                         "boards_per_launch": boards / launches, "avg_launch_ms": avg_ms, "launches": launches,
                          "concurrent_launches": overlap, "busy_ms": union_ms,
-                         # the same without the overlap factor: one launch's flops / its own duration (the launches of the
-                         # three slot groups share the machine, so this is a per-launch share, not the machine's rate)
-                         "per_launch_frac": fpb * st["infer_boards"] / launches / (avg_ms * 1e-3) / 1e12 / peak if avg_ms > 0 else None,
-                         "infer_share_of_wall": union_ms * 1e-3 / dt if dt > 0 else None,
-                         # Connect-4 kernels skip the 3x3 taps that a whole 32-row tile lacks (exact zeros): 3 of 18
-                         # tile-taps per residual conv.  `achieved` stays algorithmic; this is the executed share.
-                         "executed_flops_per_board": fpb - (2.0 * cells * 2 * args.blocks * args.channels * args.channels * 9 / 6.0
-                                                            if args.game == "connect4" else 0.0),
-                         },
+                         # the same without the overlap factor: one launch's executed flops / its own duration (the
+                         # launches of the slot groups share the machine: a per-launch share, not the machine's rate)
+                         "per_launch_frac": tf(efpb * boards / launches, avg_ms) / peak if avg_ms > 0 else None,
+                         "infer_share_of_wall": union_ms * 1e-3 / dt if dt > 0 else None},
             "tree": tree_report(st, dt, n_act),
         }
 
@@ -302,16 +388,14 @@ def main() -> None:
                 ghz, span = pe.probe_clock(pb)
             rl["held_clock_ghz"] = ghz
             rl["peak_at_held_clock"] = rl["peak"] * ghz / 2.4
-            rl["frac_at_held_clock"] = rl["achieved"] / rl["peak_at_held_clock"]
-            # f16x2 executes three fp16 MFMAs per algorithmic multiply-add (hi*hi, hi*lo, lo*hi)
-            rl["executed_frac_at_held_clock"] = (rl["frac_at_held_clock"] * rl["executed_flops_per_board"] / rl["flops_per_board"]
-                                                 * (3.0 if precision == "f16x2" else 1.0))
+            rl["frac_at_held_clock"] = rl["achieved"] / rl["peak_at_held_clock"]      # executed FLOP against the clock the chip held
         except Exception as exc:        # noqa: BLE001  the probe is an extra, never a reason to lose the bench line
             rl["held_clock_ghz"] = None
             rl["held_clock_error"] = str(exc)
 
     probe_ok = args.game == "connect4" and 32 < args.channels <= 64 and rank == 0 and not args.no_clock_probe
-    head = measure(args.precision)
+    cache_ok = args.game == "connect4" and not args.no_eval_cache
+    head = measure(args.precision, eval_cache=args.eval_cache_headline and cache_ok)
     if probe_ok:
         probe_clock(head, args.precision)
     other = None
@@ -320,26 +404,46 @@ def main() -> None:
         other = measure(other_precision)
         if probe_ok:
             probe_clock(other, other_precision)
+    # the evaluation cache (identical episodes, fewer executed evaluations): reported beside the headline, never as it
+    cached = {}
+    if cache_ok and not args.eval_cache_headline:
+        for prec in ([args.precision] if args.single else ["f32", "f16x2"]):
+            cached[prec] = measure(prec, eval_cache=True)
 
     if rank == 0:
+        keys = ("value", "unit", "ms_per_step", "dtype", "evals", "evals_executed", "roofline", "tree")
         out = {
             "metric": "self-play episodes/sec (Connect-4, 100 sims/move)" if (args.sims == 100 and args.game == "connect4") else
                       f"self-play episodes/sec ({args.game}, {args.sims} sims/move)",
             "value": head["value"], "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": head["dtype"], "data": "synthetic (empty-board starts, random-weight net, seeded RNG)",
+            "dtype": head["dtype"],
+            "data": "REHEARSAL: fabricated records, no engine, no GPU (launcher / collective plumbing only)" if rehearse else
+                    "synthetic (empty-board starts, random-weight net, seeded RNG)",
             "config": {"workload": f"{args.game} self-play, ResNet {args.channels}ch/{args.blocks}blk random weights, "
                                    f"{args.sims} sims/move, {args.slots} concurrent games per GPU, first "
-                                   f"{args.slots} completions per GPU per step",
+                                   f"{args.slots} completions per GPU per step"
+                                   + (", evaluation cache ON" if args.eval_cache_headline and cache_ok else ""),
                        "slots_per_gpu": args.slots, "sims": args.sims, "parallelism": f"game-sharded x{world}",
                        "episodes": head["episodes"], "samples": head["samples"],
-                       "mean_plies_per_episode": head["samples"] / max(head["episodes"], 1)},
+                       "mean_plies_per_episode": head["samples"] / max(head["episodes"], 1),
+                       "launched_by": "bench.py (own torch.distributed.run child)" if os.environ.get("AZSP_BENCH_SELF_LAUNCHED") == "1"
+                                      else ("external launcher" if "WORLD_SIZE" in os.environ else "single process")},
             "ranks": head["ranks"],
             "roofline": head["roofline"], "tree": head["tree"],
         }
+        if rehearse:
+            out["rehearsal"] = True
+        for k in ("evals", "evals_executed", "eval_cache"):
+            if k in head:
+                out[k] = head[k]
         if other is not None:
             key = "f16x2" if args.precision == "f32" else "f32"
-            out[key] = {k: other[k] for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "tree")}
+            out[key] = {k: other[k] for k in keys}
+        if cached:
+            out["eval_cache"] = {"note": "AZSP_FLAG_EVAL_CACHE: every position evaluated at most once per generate_episodes call; "
+                                         "episodes identical to the headline's (tests), roofline on EXECUTED evaluations only",
+                                 **{prec: {k: r[k] for k in keys + ("eval_cache",)} for prec, r in cached.items()}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.sims, args.cpu_slots, net.state_dict())
         if "cpu_baseline" in out:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AZSP_ABI_VERSION 2
+#define AZSP_ABI_VERSION 3
 
 typedef struct azsp_engine azsp_engine;
 
@@ -77,6 +77,26 @@ enum { AZSP_OK = 0, AZSP_ERR_ARG = -1, AZSP_ERR_HIP = -2, AZSP_ERR_STATE = -3, A
                                     A*(n_sims+1) to A*(n_sims+1)*max_plies (HBM is sized for it).  Root noise is only
                                     mixed in where a root is expanded afresh.                                   */
 
+#define AZSP_FLAG_EVAL_CACHE 8u  /* NOT in the reference, and invisible in its results: every position is evaluated at most
+                                    ONCE per generation run.  The reference evaluates every leaf of every game in every
+                                    round (monte_carlo_tree_search.py:154-157) and rebuilds every tree every ply (:116-123)
+                                    with no noise, so equal positions -- the 4096 identical first plies, transpositions,
+                                    the part of last ply's tree below the move just played -- are evaluated over and over
+                                    with identical results.  The device evaluators are deterministic and bitwise independent
+                                    of the batch a position sits in, so a position -> (p, v) table in HBM (filled by the
+                                    inference kernel, probed by the tree kernels) changes NO bit of any visit count, move or
+                                    episode (tested on against off); azsp_stats then reports the reference's evaluation
+                                    count (evals) and the executed one (evals_executed) side by side.  Cleared by azsp_reset,
+                                    azsp_load_resnet and azsp_set_evaluator.  Device evaluators only (AZSP_EVAL_HOST runs
+                                    without it); games with an injective 64-bit position key (Connect-4, Connect2).  */
+
+/* Diagnostics switches: the environment variable AZSP_DIAG, read ONCE per engine by azsp_create, may hold
+ *   no_fused_rounds  runs of up to 32 games use the two-launch simulation rounds of larger runs instead of the one-launch
+ *                    form (same results; the tests compare the two)
+ *   unfused_tree     device evaluators use the four-launch slot-ordered rounds of the host evaluator (same results)
+ * Nothing else in the product library reads the environment except AZSP_RESNET_VARIANT / AZSP_F16_WR (kernel-variant
+ * choice among variants that return the same bits) and AZSP_RESNET_TRACE / AZSP_PROBE_VERBOSE (phase-time printouts). */
+
 typedef struct azsp_config {
     uint32_t struct_size;    /* sizeof(azsp_config), for forward compatibility                       */
     int32_t  game;           /* AZSP_GAME_*                                                           */
@@ -92,7 +112,8 @@ typedef struct azsp_config {
     int32_t  arena_episodes; /* episode capacity of the output arena; 0 = n_slots.  The sharded exact mode
                                 (azsp_play_begin/commit) lets one shard emit more than its own n_slots.    */
     int32_t  search_rules;   /* AZSP_RULES_*                                                           */
-    int32_t  reserved;       /* 0                                                                      */
+    int32_t  eval_cache_entries; /* AZSP_FLAG_EVAL_CACHE: table entries (64 B each, rounded up to a power of two,
+                                    at most 2^26); 0 = automatic (16 * n_slots * (n_sims + 1))              */
 } azsp_config;
 
 /* Host evaluator: boards int8[n][cells] (canonical) -> p float32[n][n_actions], v float32[n].
@@ -115,7 +136,8 @@ typedef struct azsp_ply_result {
 
 typedef struct azsp_stats {
     uint64_t plies, rounds;            /* azsp_search calls, simulation rounds                       */
-    uint64_t evals;                    /* boards evaluated by the evaluator (roots + leaves)         */
+    uint64_t evals;                    /* positions that needed the evaluator (roots + leaves): what the reference
+                                          evaluates, whether or not AZSP_FLAG_EVAL_CACHE found some of them done */
     uint64_t terminal_leaves;          /* simulations that ended on a terminal leaf (no evaluation)  */
     uint64_t infer_launches;           /* launches of the dominant inference kernel                  */
     double   infer_ms;                 /* sum of their HIP-event durations (AZSP_FLAG_TIMING)        */
@@ -125,6 +147,13 @@ typedef struct azsp_stats {
     uint64_t path_nodes;               /* sum of backup path lengths (for algorithmic bytes)         */
     double   infer_union_ms;           /* time during which >= 1 inference launch was running (launches
                                           of different slot groups overlap)                            */
+    uint64_t evals_executed;           /* positions actually evaluated (== evals without AZSP_FLAG_EVAL_CACHE; with it
+                                          the count can vary by a few between identical runs: two slot groups that
+                                          meet the same new position in the same search both evaluate it) */
+    double   infer_exec_flops_per_board;   /* matrix-pipe FLOP the selected inference kernel variant EXECUTES per board
+                                          slot of a full workgroup: padding rows included, statically skipped
+                                          off-board taps excluded, x 3 for the split-fp16 kernel (hi*hi, hi*lo, lo*hi) */
+    uint64_t eval_cache_entries;       /* table size in use (0 = cache off)                              */
 } azsp_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

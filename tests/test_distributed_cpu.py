@@ -130,3 +130,40 @@ def test_all_gather_variable_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert results == {0: True, 1: True}
+
+
+def _run_bench(args, env_extra, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus2_without_a_launcher_starts_two_ranks_and_prints_one_line():
+    """`python bench.py --gpus 2` with no launcher environment must not measure one GPU and call it two: it starts its
+    own two rank processes (torch.distributed.run child, before anything touches a GPU) and rank 0 prints ONE JSON line
+    with n_gpus 2.  Run here in rehearsal mode (AZSP_BENCH_REHEARSE=1: fabricated records, gloo, no engine), which goes
+    through the real launcher, rendezvous, fences, variable-length all-gather and rank combination."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--slots", "8"], {"AZSP_BENCH_REHEARSE": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rehearsal"] is True and out["steps"] == 2
+    assert len(out["ranks"]["ms_per_step"]) == 2 and out["config"]["launched_by"].startswith("bench.py")
+    assert out["config"]["episodes"] == 2 * 2 * 8            # both ranks' episodes, both steps
+    assert out["value"] == 0.0 and "REHEARSAL" in out["data"]
+
+
+def test_bench_never_reports_more_gpus_than_it_ran_on():
+    """--gpus N is refused (non-zero exit, no JSON line) when fewer than N GPUs are visible, and when a launcher started
+    a different number of ranks than --gpus names (the round-2 form silently measured one GPU)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = _run_bench(["--gpus", "2"], {})
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and "{" not in r.stdout
+    r = _run_bench(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and "{" not in r.stdout

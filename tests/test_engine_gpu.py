@@ -53,12 +53,14 @@ def _check_run(out, run):
                 assert float(out["prior"][i, a]) == k["prior"], (i, a)
 
 
-def test_run_batch_matches_reference_fixtures(azsp):
+@pytest.mark.parametrize("cache", [False, True], ids=["nocache", "evalcache"])
+def test_run_batch_matches_reference_fixtures(azsp, cache):
     for run in load_json("search_hash.json")["runs"]:
         boards = np.array(run["boards"], dtype=np.int8)
-        with _engine(azsp, run["game"], len(boards), run["sims"], hash_salt=run["salt"]) as e:
+        with _engine(azsp, run["game"], len(boards), run["sims"], hash_salt=run["salt"], eval_cache=cache) as e:
             e.use_hash_evaluator()
             _check_run(e.run_batch(boards), run)
+            _check_run(e.run_batch(boards), run)        # again on the same engine (the cache now holds every position)
 
 
 def test_mcts_facade_matches_reference_fixtures(azsp):
@@ -92,8 +94,9 @@ def _episodes_equal(eps, golden):
         assert all(s.state.dtype == np.int64 and s.policy.dtype == np.float64 for s in ep.samples)
 
 
+@pytest.mark.parametrize("cache", [False, True], ids=["nocache", "evalcache"])
 @pytest.mark.parametrize("model_cls", [HashStub, HostOnlyModel])
-def test_generate_episodes_matches_reference_fixtures(azsp, model_cls):
+def test_generate_episodes_matches_reference_fixtures(azsp, model_cls, cache):
     """Drop-in EpisodeGenerator vs transcripts of the reference's generate_episodes: states, pi, z,
     yield order and the number of RNG draws, with the device evaluator and the host-callback path."""
     games = {"connect4": azsp.Connect4Game, "connect2": azsp.Connect2Game}
@@ -102,17 +105,23 @@ def test_generate_episodes_matches_reference_fixtures(azsp, model_cls):
             continue            # python callback per round: keep the slow path small
         cfg = azsp.AlphaZeroConfig(batch_size=32, num_iterations=1, num_simulations=run["sims"],
                                    num_episodes=run["n"], num_iters_for_train_history=1, epochs=1)
-        gen = azsp.EpisodeGenerator(game=games[run["game"]](), config=cfg)
+        gen = azsp.EpisodeGenerator(game=games[run["game"]](), config=cfg, eval_cache=cache)     # (host callback: runs without it)
         np.random.seed(run["seed"])
         eps = list(gen.generate_episodes(model_cls(run["game"], run["salt"])))
         assert float(np.random.random_sample()) == run["rng_after"]
         _episodes_equal(eps, run["episodes"])
+        st = gen.last_stats
+        if cache and model_cls is HashStub:
+            assert st["evals_executed"] < st["evals"] or st["evals"] < 4
+        else:
+            assert st["evals_executed"] == st["evals"]
 
 
-def test_per_ply_root_counts_match_reference_fixtures(azsp):
+@pytest.mark.parametrize("cache", [False, True], ids=["nocache", "evalcache"])
+def test_per_ply_root_counts_match_reference_fixtures(azsp, cache):
     run = [r for r in load_json("episodes_hash.json")["runs"] if r["game"] == "connect4" and r["n"] == 16][0]
     np.random.seed(run["seed"])
-    with _engine(azsp, "connect4", run["n"], run["sims"], hash_salt=run["salt"]) as e:
+    with _engine(azsp, "connect4", run["n"], run["sims"], hash_salt=run["salt"], eval_cache=cache) as e:
         e.use_hash_evaluator()
         e.reset()
         for ply in run["plies"]:
@@ -127,12 +136,13 @@ def test_per_ply_root_counts_match_reference_fixtures(azsp):
 
 @pytest.mark.parametrize("n,sims,seed,salt,groups", [(512, 100, 11, 3, 1), (512, 100, 11, 3, 4), (2048, 30, 15, 2, 0),
                                                      (64, 400, 12, 8, 0), (1, 100, 13, 0, 0), (3, 1, 14, 1, 0)])
-def test_generate_matches_c_oracle_at_larger_sizes(azsp, n, sims, seed, salt, groups):
+@pytest.mark.parametrize("cache", [False, True], ids=["nocache", "evalcache"])
+def test_generate_matches_c_oracle_at_larger_sizes(azsp, n, sims, seed, salt, groups, cache):
     """Also covers the multi-stream slot groups: results must not depend on the grouping."""
     ref = co.generate("connect4", sims, n, salt, seed=seed, trace=False)
     cfg = azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1)
     np.random.seed(seed)
-    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg, n_groups=groups)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg, n_groups=groups, eval_cache=cache)
     eps = list(gen.generate_episodes(HashStub("connect4", salt)))
     assert float(np.random.random_sample()) == ref["next_uniform"]
     assert len(eps) == n
@@ -142,8 +152,9 @@ def test_generate_matches_c_oracle_at_larger_sizes(azsp, n, sims, seed, salt, gr
         assert np.array_equal(np.stack([s.policy for s in ep.samples]), ref["policies"][lo:hi])
         assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()
     st = gen.last_stats
-    assert st["evals"] == ref["stats"][0] and st["terminal_leaves"] == ref["stats"][1]
+    assert st["evals"] == ref["stats"][0] and st["terminal_leaves"] == ref["stats"][1]      # the reference's evaluation count
     assert st["path_nodes"] == ref["stats"][3]
+    assert st["evals_executed"] == st["evals"] if not cache else st["evals_executed"] <= st["evals"]
 
 
 # ------------------------------------------------------------------------------------ network
@@ -202,8 +213,9 @@ def test_resnet_forward_matches_reference_vectors(azsp, tag, f16):
     assert np.all(np.abs(p.sum(axis=1) - 1) < 1e-6)
 
 
+@pytest.mark.parametrize("cache", [False, True], ids=["nocache", "evalcache"])
 @pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
-def test_resnet_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp, f16):
+def test_resnet_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp, f16, cache):
     """End-to-end with the real network: the C oracle runs the reference algorithm on the CPU but asks
     the DEVICE kernel for (P, V) through the C ABI; the engine runs everything on the GPU.  Both see
     identical floats, so visit counts, moves, pi and z must be bit-identical."""
@@ -222,7 +234,7 @@ def test_resnet_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp, f16):
 
     np.random.seed(seed)
     gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1),
-                                f16_split=f16)
+                                f16_split=f16, eval_cache=cache)
     eps = list(gen.generate_episodes(Net()))
     assert float(np.random.random_sample()) == ref["next_uniform"]
     for e, ep in enumerate(eps):
@@ -374,15 +386,19 @@ def test_resnet_every_batch_regime_returns_the_same_bits(azsp, blocks, ch, f16):
 
 
 # ------------------------------------------------------------------------------------ full size
-def test_full_size_config2_properties(azsp):
+@pytest.mark.parametrize("f16,cache", [(False, False), (True, False), (False, True), (True, True)],
+                         ids=["f32", "f16x2", "f32-evalcache", "f16x2-evalcache"])
+def test_full_size_config2_properties(azsp, f16, cache):
     """BASELINE.json configs[1]: Connect-4, 64-ch/4-block ResNet, 100 sims, 4096 concurrent games.
-    Too large for the oracle; checked through size-independent invariants of every episode."""
+    Too large for the oracle; checked through size-independent invariants of every episode (both inference kernels,
+    with and without the evaluation cache)."""
     import torch
     torch.manual_seed(0)
     net = azsp.ResNet((6, 7), 7, 4, 64)
     n, sims = 4096, 100
     np.random.seed(0)
-    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), f16_split=f16,
+                                eval_cache=cache)
     eps = list(gen.generate_episodes(net))
     assert len(eps) == n
     rules = oz.C4Rules()
@@ -408,13 +424,14 @@ def _full_size_invariants(azsp, game, rules, net, n, sims, stride, **gen_kw):
     return eps, st
 
 
-def test_full_size_config3_properties(azsp):
+@pytest.mark.parametrize("f16,cache", [(False, False), (True, False), (True, True)], ids=["f32", "f16x2", "f16x2-evalcache"])
+def test_full_size_config3_properties(azsp, f16, cache):
     """BASELINE.json configs[2]: Connect-4, 64-ch/4-block ResNet, 400 sims, 8192 concurrent games on one GPU (the
     deep-tree backup stress: up to 2808 nodes per tree, 0.46 GB of trees), through the same invariants as config 2."""
     import torch
     torch.manual_seed(0)
     net = azsp.ResNet((6, 7), 7, 4, 64)
-    eps, st = _full_size_invariants(azsp, azsp.Connect4Game(), oz.C4Rules(), net, 8192, 400, 23)
+    eps, st = _full_size_invariants(azsp, azsp.Connect4Game(), oz.C4Rules(), net, 8192, 400, 23, f16_split=f16, eval_cache=cache)
     assert st["path_nodes"] / (st["evals"] + st["terminal_leaves"]) > 3.0      # deeper trees than at 100 sims
 
 
@@ -427,21 +444,25 @@ def test_full_size_config4_one_gpu_shard_properties(azsp):
     _full_size_invariants(azsp, azsp.Connect4Game(), oz.C4Rules(), net, 4096, 100, 11)
 
 
-def test_config4_network_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp):
+@pytest.mark.parametrize("cache", [False, True], ids=["nocache", "evalcache"])
+@pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
+def test_config4_network_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp, f16, cache):
     """configs[3]'s network (8 blocks x 128 channels) in the loop, at a size the oracle finishes: 32 games x 100 sims;
-    the C oracle asks the device kernel for (P, V), so counts, moves, pi, z and the RNG position must be identical."""
+    the C oracle asks the device kernel (fp32 or f16x2) for (P, V), so counts, moves, pi, z and the RNG position must be
+    identical -- with and without the evaluation cache."""
     import torch
     from azsp.weights import resnet_blob
     torch.manual_seed(3)
     net = azsp.ResNet((6, 7), 7, 8, 128).eval()
     blob, blocks, ch = resnet_blob(net)
     n, sims, seed = 32, 100, 5
-    with _engine(azsp, "connect4", 64, 1, res_blocks=blocks, channels=ch) as pe:
+    with _engine(azsp, "connect4", 64, 1, res_blocks=blocks, channels=ch, f16_split=f16) as pe:
         pe.load_resnet(blob)
         cb = co.make_predict_cb(lambda bs: pe.predict(np.stack(bs)), (6, 7), 7)
         ref = co.generate("connect4", sims, n, seed=seed, predict_cb=cb, trace=False)
     np.random.seed(seed)
-    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), f16_split=f16,
+                                eval_cache=cache)
     eps = list(gen.generate_episodes(net))
     assert float(np.random.random_sample()) == ref["next_uniform"]
     _assert_equals_c_oracle(eps, ref, n)
@@ -516,7 +537,9 @@ def test_gomoku_device_network_with_several_slot_groups(azsp, blocks, ch):
             assert np.array_equal(searched[0][k], other[k]), k
 
 
-def test_real_network_transcript_of_the_reference_config1(azsp):
+@pytest.mark.parametrize("f16,cache", [(False, False), (True, False), (False, True), (True, True)],
+                         ids=["f32", "f16x2", "f32-evalcache", "f16x2-evalcache"])
+def test_real_network_transcript_of_the_reference_config1(azsp, f16, cache):
     """tests/golden/episodes_resnet.json: the REFERENCE's generate_episodes with its own torch-CPU ResNet(4, 64)
     (BASELINE.json configs[0]: 25 sims, one game, seeds 0 / 0; episode_generator.py:23-87 + resnet.py:130-157).  The
     engine plays the same game with the same weights on the device network: per-ply root visit counts, chosen moves,
@@ -533,7 +556,7 @@ def test_real_network_transcript_of_the_reference_config1(azsp):
     rules = oz.C4Rules()
     np.random.seed(run["seed"])
     states, pols = [], []
-    with _engine(azsp, "connect4", n, sims, res_blocks=blocks, channels=ch) as e:
+    with _engine(azsp, "connect4", n, sims, res_blocks=blocks, channels=ch, f16_split=f16, eval_cache=cache) as e:
         e.load_resnet(blob)
         e.reset()
         board, player = rules.init_board(), 1
@@ -541,7 +564,7 @@ def test_real_network_transcript_of_the_reference_config1(azsp):
             e.search()
             counts = e.root_counts()[0].tolist()
             if counts != ply["counts"][0]:
-                with _engine(azsp, "connect4", 64, 1, res_blocks=blocks, channels=ch) as pe:
+                with _engine(azsp, "connect4", 64, 1, res_blocks=blocks, channels=ch, f16_split=f16) as pe:
                     pe.load_resnet(blob)
                     gap = min_puct_margin(rules, lambda bs: tuple(map(list, pe.predict(np.stack(bs)))), sims,
                                           rules.canonical(board, player))
@@ -565,7 +588,8 @@ def test_real_network_transcript_of_the_reference_config1(azsp):
         def state_dict(self):
             return {k: v for k, v in sd.items() if "num_batches_tracked" not in k}
     np.random.seed(run["seed"])
-    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), f16_split=f16,
+                                eval_cache=cache)
     _episodes_equal(list(gen.generate_episodes(Net())), run["episodes"])
     assert float(np.random.random_sample()) == run["rng_after"]
 
@@ -600,53 +624,13 @@ def test_device_dataset_and_json_writer_match_reference_output(azsp, tmp_path):
     assert load_episodes(os.path.join(GOLDEN, "episodes_wire.json")) == eps
 
 
-def test_fused_rounds_bit_exact_vs_oracle_and_vs_two_launch_rounds(azsp, monkeypatch):
-    """Large slot groups of the exact-fp32 Connect-4 network can run FUSED rounds (opt-in, AZSP_FUSED_ROUNDS=1; measured
-    slower than the default two launches per round, kept as a tested alternative): the inference kernel expands the leaves it
-    evaluated and finds those games' next leaves itself, a game that hits terminal leaves doing several simulations in
-    one launch.  No result may change: 1024 games (one group) against the C oracle fed by the device network, and a
-    3-group run against the same engine with the two-launch rounds (AZSP_FUSED_ROUNDS=0), bit for bit, including the
-    evaluation accounting."""
-    import torch
-    from azsp.weights import resnet_blob
-    monkeypatch.setenv("AZSP_FUSED_ROUNDS", "1")            # opt-in (read when an engine is created)
-    torch.manual_seed(11)
-    net = azsp.ResNet((6, 7), 7, 2, 64).eval()
-    blob, blocks, ch = resnet_blob(net)
-    n, sims, seed = 1024, 10, 4
-    with _engine(azsp, "connect4", 1024, 1, res_blocks=blocks, channels=ch) as pe:
-        pe.load_resnet(blob)
-        cb = co.make_predict_cb(lambda bs: pe.predict(np.stack(bs)), (6, 7), 7)
-        ref = co.generate("connect4", sims, n, seed=seed, predict_cb=cb, trace=False)
-    np.random.seed(seed)
-    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), n_groups=1)
-    eps = list(gen.generate_episodes(net))
-    assert float(np.random.random_sample()) == ref["next_uniform"]
-    _assert_equals_c_oracle(eps, ref, n)
-    st = gen.last_stats
-    assert st["select_launches"] == 0 and st["infer_launches"] == st["plies"] * (sims + 1)      # one launch per round
-    assert st["evals"] == ref["stats"][0] and st["terminal_leaves"] == ref["stats"][1] and st["path_nodes"] == ref["stats"][3]
-
-    def run(fused):
-        monkeypatch.setenv("AZSP_FUSED_ROUNDS", "1" if fused else "0")
-        np.random.seed(9)
-        g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, 40, 3000, 1, 1))
-        out = list(g.generate_episodes(net))
-        return out, g.last_stats, float(np.random.random_sample())
-    a, sa, ra = run(True)
-    b, sb, rb = run(False)
-    assert sa["select_launches"] == 0 and sb["select_launches"] > 0
-    assert ra == rb and a == b
-    assert (sa["evals"], sa["terminal_leaves"], sa["path_nodes"]) == (sb["evals"], sb["terminal_leaves"], sb["path_nodes"])
-
-
 def test_small_batches_run_fused_rounds_by_default(azsp, monkeypatch):
-    """A few games (up to 32: one-board inference kernels) run ONE launch per simulation round unless AZSP_FUSED_ROUNDS=0:
-    a round there is launch latency.  Same episodes, RNG position and evaluation accounting as the two-launch rounds, and
+    """A few games (up to 32: one-board inference kernels) run ONE launch per simulation round unless the diagnostics
+    switch AZSP_DIAG=no_fused_rounds is set: a round there is launch latency.  Same episodes, RNG position and evaluation accounting as the two-launch rounds, and
     bit-exact against the C oracle fed by the device network; large batches keep two launches per round by default."""
     import torch
     from azsp.weights import resnet_blob
-    monkeypatch.delenv("AZSP_FUSED_ROUNDS", raising=False)
+    monkeypatch.delenv("AZSP_DIAG", raising=False)
     torch.manual_seed(5)
     net = azsp.ResNet((6, 7), 7, 2, 64).eval()
     blob, blocks, ch = resnet_blob(net)
@@ -658,52 +642,32 @@ def test_small_batches_run_fused_rounds_by_default(azsp, monkeypatch):
 
     def run(env):
         if env is None:
-            monkeypatch.delenv("AZSP_FUSED_ROUNDS", raising=False)
+            monkeypatch.delenv("AZSP_DIAG", raising=False)
         else:
-            monkeypatch.setenv("AZSP_FUSED_ROUNDS", env)
+            monkeypatch.setenv("AZSP_DIAG", env)
         np.random.seed(seed)
         g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
         out = list(g.generate_episodes(net))
         return out, g.last_stats, float(np.random.random_sample())
     a, sa, ra = run(None)
-    b, sb, rb = run("0")
+    b, sb, rb = run("no_fused_rounds")
     assert sa["select_launches"] == 0 and sa["infer_launches"] == sa["plies"] * (sims + 1)      # one launch per round
     assert sb["select_launches"] > 0
     assert ra == rb == ref["next_uniform"] and a == b
     _assert_equals_c_oracle(a, ref, n)
     assert (sa["evals"], sa["terminal_leaves"], sa["path_nodes"]) == (sb["evals"], sb["terminal_leaves"], sb["path_nodes"])
     assert sa["evals"] == ref["stats"][0] and sa["terminal_leaves"] == ref["stats"][1]
-    np.random.seed(3)                                        # a large batch: two launches per round by default
+    monkeypatch.delenv("AZSP_DIAG", raising=False)
+    np.random.seed(3)                                        # a large batch: two launches per round
     g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, 5, 3000, 1, 1))
-    list(g.generate_episodes(net))
+    big = list(g.generate_episodes(net))
     assert g.last_stats["select_launches"] > 0
-
-
-def test_graph_replay_of_a_search_changes_nothing(azsp, monkeypatch):
-    """AZSP_GRAPH=1: from its second search on, an engine replays one ply's launches as a captured HIP graph (measured: no
-    faster than the streams -- kept as a tested option).  Same episodes, RNG position and accounting as without it."""
-    import torch
-    torch.manual_seed(2)
-    net = azsp.ResNet((6, 7), 7, 2, 64).eval()
-
-    def run(env, n, sims):
-        monkeypatch.setenv("AZSP_GRAPH", env)
-        np.random.seed(17)
-        g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
-        out = list(g.generate_episodes(net))
-        return out, g.last_stats, float(np.random.random_sample())
-    for n, sims in ((6, 20), (700, 12)):                       # fused one-board rounds; three groups on three streams
-        a, sa, ra = run("1", n, sims)
-        b, sb, rb = run("0", n, sims)
-        assert a == b and ra == rb
-        for k in ("plies", "evals", "terminal_leaves", "path_nodes", "infer_launches", "select_launches", "expand_launches"):
-            assert sa[k] == sb[k], k
-    monkeypatch.setenv("AZSP_GRAPH", "1")
-    ref = co.generate("connect4", 15, 40, salt=77, seed=5, trace=False)
-    np.random.seed(5)
-    g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, 15, 40, 1, 1))
-    eps = list(g.generate_episodes(HashStub("connect4", 77)))
-    _assert_equals_c_oracle(eps, ref, 40)
+    # the other diagnostics switch: device evaluators on the host evaluator's four-launch slot-ordered rounds
+    monkeypatch.setenv("AZSP_DIAG", "unfused_tree")
+    np.random.seed(3)
+    g4 = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, 5, 3000, 1, 1))
+    assert list(g4.generate_episodes(net)) == big
+    assert g4.last_stats["expand_launches"] > g.last_stats["expand_launches"]
 
 
 def test_error_paths(azsp):
@@ -868,14 +832,14 @@ def test_reference_mcts_tests_intent_on_the_engine(azsp):
         assert root.visit_count == sims and float(root.value_sum) == float(ref.w)
 
 
-@pytest.mark.parametrize("seed,salt", [(101, 11), (102, 12)])
-def test_large_randomised_differential_run(azsp, seed, salt):
+@pytest.mark.parametrize("seed,salt,cache", [(101, 11, False), (102, 12, False), (102, 12, True)])
+def test_large_randomised_differential_run(azsp, seed, salt, cache):
     """A longer differential run (2048 games x 150 sims, ~9 M simulations per seed) against the C oracle: any
     rare divergence (ties, deep trees, slot restarts late in the run) would show as a mismatch."""
     n, sims = 2048, 150
     ref = co.generate("connect4", sims, n, salt, seed=seed, trace=False)
     np.random.seed(seed)
-    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), eval_cache=cache)
     eps = list(gen.generate_episodes(HashStub("connect4", salt)))
     assert float(np.random.random_sample()) == ref["next_uniform"]
     flat_s = np.concatenate([np.stack([s.state for s in ep.samples]).reshape(len(ep), -1) for ep in eps])
@@ -888,7 +852,8 @@ def test_large_randomised_differential_run(azsp, seed, salt):
 
 @pytest.mark.parametrize("opts", [{"sampling_plies": 6}, {"dirichlet_alpha": 0.8, "dirichlet_eps": 0.25},
                                   {"sampling_plies": 0}, {"sampling_plies": 4, "dirichlet_alpha": 0.3, "dirichlet_eps": 0.4}])
-def test_search_options_beyond_the_reference(azsp, opts):
+@pytest.mark.parametrize("cache", [False, True], ids=["nocache", "evalcache"])
+def test_search_options_beyond_the_reference(azsp, opts, cache):
     """Temperature cut-off and root noise do not exist in the reference's generator, so the
     reference cannot pin them: they are pinned against the oracle's documented extension, bit for bit, and
     are off by default (every other test runs the reference's behaviour)."""
@@ -898,7 +863,7 @@ def test_search_options_beyond_the_reference(azsp, opts):
     ref = list(oz.generate_episodes(rules, oz.HashModel(rules, salt).predict, sims, n, **opts))
     after = float(np.random.random_sample())
     np.random.seed(seed)
-    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), **opts)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), eval_cache=cache, **opts)
     eps = list(gen.generate_episodes(HashStub("connect4", salt)))
     assert float(np.random.random_sample()) == after
     assert len(eps) == len(ref) == n
@@ -1112,3 +1077,96 @@ def test_c_abi_rejects_bad_arguments_with_messages(azsp):
         assert lib.azsp_search(h) == 0 and lib.azsp_play(h, u, C.byref(res)) == 0 and res.ply == 0
     finally:
         lib.azsp_destroy(h)
+
+
+# ------------------------------------------------------------------------------------ evaluation cache
+def _run_gen(azsp, net, n, sims, seed, **kw):
+    np.random.seed(seed)
+    g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), **kw)
+    eps = list(g.generate_episodes(net))
+    return eps, g.last_stats, float(np.random.random_sample())
+
+
+@pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
+def test_eval_cache_identical_episodes_at_2048x100_and_fewer_evaluations(azsp, f16):
+    """AZSP_FLAG_EVAL_CACHE must be invisible in the results: 2048 games x 100 sims with the 4 x 64 device network, cache
+    off and on -- the same episodes in the same order, the same RNG position, the same reference-equivalent accounting
+    (evals, terminal leaves, path nodes) -- while the number of evaluations actually executed drops (the 2048 identical
+    first plies, transpositions, last ply's subtree).  Twice on the same generator: the second call starts from an empty
+    table again (a position is never carried over between generation runs)."""
+    import torch
+    torch.manual_seed(0)
+    net = azsp.ResNet((6, 7), 7, 4, 64).eval()
+    n, sims = 2048, 100
+    off, s_off, r_off = _run_gen(azsp, net, n, sims, 7, f16_split=f16)
+    np.random.seed(7)
+    g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), f16_split=f16, eval_cache=True)
+    on = list(g.generate_episodes(net))
+    s_on, r_on = g.last_stats, float(np.random.random_sample())
+    assert on == off and r_on == r_off
+    for k in ("plies", "rounds", "evals", "terminal_leaves", "path_nodes"):
+        assert s_on[k] == s_off[k], k
+    assert s_off["evals_executed"] == s_off["evals"] and s_off["eval_cache_entries"] == 0
+    assert s_on["evals_executed"] < 0.6 * s_on["evals"] and s_on["eval_cache_entries"] >= 1024
+    print(f"[eval-cache] 2048 x 100, f16x2={f16}: {s_on['evals']} reference evaluations, {s_on['evals_executed']} executed "
+          f"({s_on['evals'] / s_on['evals_executed']:.2f}x fewer)")
+    first = s_on["evals_executed"]
+    eng = g.engine_for(net)
+    eng.reset_stats()
+    np.random.seed(7)
+    assert list(g.generate_episodes(net)) == off
+    again = g.last_stats["evals_executed"]
+    assert abs(again - first) <= 0.01 * first      # (two slot groups meeting one new position in one search both evaluate it)
+
+
+def test_eval_cache_edge_cases(azsp):
+    """A table far too small for the run (fills up: later positions fall back to their slots' private entries), boards
+    without a key (a floating stone: MCTS.run_batch accepts anything), tree reuse on top, new weights on a live
+    engine, and the games it does not exist for."""
+    from azsp._lib import AzspError
+    # 1. table of 1024 entries for ~0.5 M evaluations
+    n, sims, seed, salt = 512, 60, 31, 6
+    ref = co.generate("connect4", sims, n, salt, seed=seed, trace=False)
+    np.random.seed(seed)
+    g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), eval_cache=True,
+                              eval_cache_entries=1024)
+    eps = list(g.generate_episodes(HashStub("connect4", salt)))
+    assert float(np.random.random_sample()) == ref["next_uniform"]
+    _assert_equals_c_oracle(eps, ref, n)
+    st = g.last_stats
+    assert st["eval_cache_entries"] == 1024 and st["evals"] == ref["stats"][0] and st["evals_executed"] > 0.5 * st["evals"]
+    # 2. boards with floating stones have no key: searched from private entries, same results as without the cache
+    rng = np.random.RandomState(3)
+    rules = oz.C4Rules()
+    boards = np.stack(random_midgame_boards(rules, rng, 24, 20)).astype(np.int8)
+    for b in boards[::2]:
+        col = int(rng.randint(0, 7))
+        if b[0, col] == 0 and b[1, col] == 0:
+            b[0, col] = 1                                  # a stone hanging in the top row
+    outs = []
+    for cache in (False, True):
+        with _engine(azsp, "connect4", 24, 80, hash_salt=5, eval_cache=cache) as e:
+            e.use_hash_evaluator()
+            outs.append(e.run_batch(boards))
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    # 3. tree reuse (the trees persist, the cache persists: two kinds of memory, one result)
+    a = _run_gen(azsp, HashStub("connect4", 9), 48, 40, 12, tree_reuse=True)
+    b = _run_gen(azsp, HashStub("connect4", 9), 48, 40, 12, tree_reuse=True, eval_cache=True)
+    assert a[0] == b[0] and a[2] == b[2]
+    # 4. new weights on a live engine void every cached row
+    import torch
+    torch.manual_seed(1)
+    net1 = azsp.ResNet((6, 7), 7, 2, 64).eval()
+    torch.manual_seed(2)
+    net2 = azsp.ResNet((6, 7), 7, 2, 64).eval()
+    g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, 30, 100, 1, 1), eval_cache=True)
+    np.random.seed(4)
+    list(g.generate_episodes(net1))
+    np.random.seed(5)
+    second = list(g.generate_episodes(net2))
+    fresh, _, _ = _run_gen(azsp, net2, 100, 30, 5)
+    assert second == fresh
+    # 5. no 64-bit key for 9x9 boards
+    with pytest.raises(AzspError, match="EVAL_CACHE"):
+        _engine(azsp, "gomoku9", 8, 10, eval_cache=True)

@@ -38,7 +38,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.azsp_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.azsp_abi_version() == _lib.ABI_VERSION == 3
     import ctypes as C
     r, c, a, mp = (C.c_int32() for _ in range(4))
     assert lib.azsp_game_info(0, C.byref(r), C.byref(c), C.byref(a), C.byref(mp)) == 0
