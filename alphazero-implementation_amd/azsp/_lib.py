@@ -40,7 +40,8 @@ class Stats(C.Structure):
                 ("infer_boards", C.c_uint64), ("select_ms", C.c_double), ("expand_ms", C.c_double),
                 ("play_ms", C.c_double), ("select_launches", C.c_uint64), ("expand_launches", C.c_uint64),
                 ("path_nodes", C.c_uint64), ("infer_union_ms", C.c_double), ("evals_executed", C.c_uint64),
-                ("infer_exec_flops_per_board", C.c_double), ("eval_cache_entries", C.c_uint64)]
+                ("infer_exec_flops_per_board", C.c_double), ("eval_cache_entries", C.c_uint64),
+                ("infer_exec_flops", C.c_double)]
 
 
 class SearchOptions(C.Structure):

@@ -216,7 +216,7 @@ static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
                 // evaluation cache: the list holds entries; positions are read from and rows written into them
                 float *row0 = v.ent[0].row;
                 resnet_forward(e->net, game, &v.ent[0].mine, (int)(sizeof(EvalEnt) / 8), v.leaf_slot + v.lo, v.nl, v.n_act, row0,
-                               (int)(sizeof(EvalEnt) / 4), row0 + 7, (int)(sizeof(EvalEnt) / 4), st);
+                               (int)(sizeof(EvalEnt) / 4), row0 + 7, (int)(sizeof(EvalEnt) / 4), st, /*by_count=*/true);
             } else {
                 // leaf positions sit in the slot records; outputs are indexed by slot, so groups never share rows
                 resnet_forward(e->net, game, reinterpret_cast<const u64 *>(v.slot + e->leaf_off), v.slot_bytes / 8, v.leaf_slot + v.lo, v.nl,
@@ -515,6 +515,12 @@ static int create_impl(azsp_engine *e) {
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->gstream[0] = e->stream;
     e->n_groups = c.n_groups > 0 ? (c.n_groups > MAX_GROUPS ? MAX_GROUPS : c.n_groups) : (c.n_slots >= 3072 ? 3 : (c.n_slots >= 1024 ? 2 : 1));
+    // Evaluation cache: a position met by several slot groups in the SAME search is evaluated once per group (a row is only
+    // read where stream order guarantees it, azsp_internal.h), and games in lock-step meet the same new positions in the
+    // same round -- measured at the headline: 2.94 x fewer evaluations with one group, 2.31 x with two, 2.16 x with three.
+    // With a third of the evaluations a round no longer fills the machine twice over, so one group's launch leaves little
+    // for a second group to overlap with: 3981 / 3595 / 3387 episodes/s (fp32), 7738 / 8070 / 8055 (f16x2).
+    if (c.n_groups <= 0 && (c.flags & AZSP_FLAG_EVAL_CACHE)) e->n_groups = (c.flags & AZSP_FLAG_F16_SPLIT) && c.n_slots >= 1024 ? 2 : 1;
     for (int k = 1; k < e->n_groups; ++k) {
         HIP_TRY(hipStreamCreateWithFlags(&e->gstream[k], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
@@ -603,9 +609,10 @@ static int create_impl(azsp_engine *e) {
     if (c.flags & AZSP_FLAG_EVAL_CACHE) {
         if (gi.W != 1 || AP != 8)
             return fail(AZSP_ERR_ARG, "AZSP_FLAG_EVAL_CACHE needs a game whose positions have an injective 64-bit key (Connect-4, Connect2)");
-        // automatic size: a generation run evaluates about n_slots * (n_sims + 1) positions per ply for ~20 plies, about a
-        // third of them distinct; 16 x the per-ply figure keeps the load factor of the linear-probing table under ~0.4
-        size_t want = c.eval_cache_entries > 0 ? (size_t)c.eval_cache_entries : (size_t)N * (size_t)(S + 1) * 16;
+        // automatic size: a generation run meets about n_slots * (n_sims + 1) positions per ply for ~30 plies, 40-50 % of
+        // them distinct (measured at the headline: 5.2 M distinct of 11.2 M); 64 x the per-ply figure keeps the load
+        // factor of the linear-probing table near 0.2, where EVAL_PROBES steps practically always suffice
+        size_t want = c.eval_cache_entries > 0 ? (size_t)c.eval_cache_entries : (size_t)N * (size_t)(S + 1) * 64;
         if (want < 1024) want = 1024;
         if (want > ((size_t)1 << 26)) want = (size_t)1 << 26;       // entry index * 16 floats stays inside int32
         int lg = 10;
@@ -1007,6 +1014,7 @@ int azsp_get_stats(azsp_engine *e, azsp_stats *out) {
     e->stats.infer_union_ms = e->infer_union_ms;
     e->stats.evals_executed = e->h_counters[4];
     e->stats.infer_boards = e->evaluator == AZSP_EVAL_RESNET ? e->h_counters[4] : 0;
+    e->stats.infer_exec_flops = e->net ? resnet_exec_flops_total(e->net, false) : 0.0;
     e->stats.infer_exec_flops_per_board = e->net ? resnet_exec_flops_per_board(e->net, e->cfg.game, e->last_infer_cap) : 0.0;
     e->stats.eval_cache_entries = e->d_ent ? (uint64_t)e->ent_table : 0;
     *out = e->stats;
@@ -1019,6 +1027,7 @@ int azsp_reset_stats(azsp_engine *e) {
     int rc = sync_stream(e);
     if (rc) return rc;
     HIP_TRY(hipMemset(e->v.counters, 0, 8 * sizeof(unsigned long long)));
+    if (e->net) (void)resnet_exec_flops_total(e->net, true);
     e->stats = azsp_stats{};
     e->rounds_host = 0;
     e->infer_union_ms = 0;

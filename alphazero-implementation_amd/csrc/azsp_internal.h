@@ -81,7 +81,7 @@ struct TreeGeo {
 // search (all group streams join the main stream at the end of every search).  A key claimed by ANOTHER group during the
 // current search is not usable yet: the game falls back to its private entry (a duplicate evaluation, same bits).
 struct alignas(64) EvalEnt { u64 key; u64 mine, theirs, pad; float row[8]; };   // row = p[0..A), value at [7]  (AP == 8 games)
-constexpr int EVAL_PROBES = 8;
+constexpr int EVAL_PROBES = 16;
 constexpr u64 EVAL_POS_MASK = (1ull << 49) - 1;
 
 // Device-resident state of one engine.
@@ -194,8 +194,10 @@ int resnet_load(ResNetDev *, const float *blob, size_t n_floats, hipStream_t s);
 size_t resnet_blob_floats(int game, int blocks, int channels);
 // evaluates the leaf positions of the slots leaf_slot[j], j < *n_leaf (<= max_leaves), into out_p[slot][AP] / out_v[slot];
 // the position of slot g: mine = leaf0 + g * board_stride (W words), theirs = the W words after it
+// by_count: pick the kernel variant by the list's length on the device (all variants enqueued, gated), not by max_leaves
 void resnet_forward(ResNetDev *, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot,
-                    const int32_t *n_leaf, int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s);
+                    const int32_t *n_leaf, int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s,
+                    bool by_count = false);
 // (results of slot g: p at out_p + g * p_stride, value at out_v + g * v_stride -- strides in floats)
 // FUSED rounds (one-board Connect-4 kernels of the fp32 network, up to 32 games): one launch evaluates the listed leaves
 // AND carries those games on to their next leaf (azsp_tree_dev.h advance_game)
@@ -205,6 +207,7 @@ void resnet_forward_fused(ResNetDev *, int game, const View &view, const u64 *le
                           hipStream_t s);
 double resnet_flops_per_board(const ResNetDev *);
 double resnet_exec_flops_per_board(const ResNetDev *, int game, int max_leaves);   // matrix-pipe FLOP executed per board (variant of that capacity)
+double resnet_exec_flops_total(const ResNetDev *, bool reset);   // summed on the device over every launch since the last reset
 // diagnostics: arm the stamped instantiation for this thread's next fp32 launch; read back its clock / span
 void resnet_trace_next();
 void resnet_trace_result(double *ghz, double *span_us);
@@ -215,6 +218,8 @@ ResNet16Dev *resnet16_create(int game, int blocks, int channels);
 void resnet16_destroy(ResNet16Dev *);
 int resnet16_load(ResNet16Dev *, const float *blob, size_t n_floats, hipStream_t s);
 void resnet16_forward(ResNet16Dev *, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
-                      int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s);
+                      int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, bool by_count = false,
+                      double *flop_acc = nullptr, double wg_flops = 0.0);
+double resnet16_wg_flops(const ResNet16Dev *, double flops_per_board);      // fp16 MFMA FLOP one 6-board workgroup executes
 
 }  // namespace azsp

@@ -125,6 +125,9 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
     off += (size_t)2 * 8 * 8 * 64 * 4;      // slack: the weight streams prefetch one block / chunk past their array
     n->blob_floats = off;
     if (hipMalloc((void **)&n->d_blob, off * sizeof(float)) != hipSuccess) { delete n; return nullptr; }
+    if (hipMalloc((void **)&n->d_flop_acc, sizeof(double)) != hipSuccess || hipMemset(n->d_flop_acc, 0, sizeof(double)) != hipSuccess) {
+        (void)hipFree(n->d_blob); delete n; return nullptr;
+    }
     if (game == 0) {
         int32_t perm[512];
         build_row_order(perm);
@@ -145,6 +148,7 @@ void resnet_destroy(ResNetDev *n) {
     if (!n) return;
     if (n->d_blob) (void)hipFree(n->d_blob);
     if (n->d_perm) (void)hipFree(n->d_perm);
+    if (n->d_flop_acc) (void)hipFree(n->d_flop_acc);
     if (n->f16) resnet16_destroy(n->f16);
     delete n;
 }
@@ -335,21 +339,35 @@ static const Variant *pick_variant(const ResNetDev *n, int game, int max_leaves)
 // per 3x3 convolution (exact zeros), the 9x9 one-board kernels compute exactly their 81 cells (80 on MFMAs, the corner
 // on the vector ALU); stem and heads are counted as in the algorithmic figure.  The split-fp16 kernel (always 6 boards,
 // tap skipping) issues three fp16 MFMAs per fp32 multiply-add.
-double resnet_exec_flops_per_board(const ResNetDev *n, int game, int max_leaves) {
-    if (!n) return 0.0;
+static double variant_wg_flops(const ResNetDev *n, const Variant *v, int *boards_per_wg) {
     const NetGeom &g = n->g;
     const double C = g.C, cells = g.cells;
     const double tower = 2.0 * cells * 2.0 * g.blocks * C * C * 9;
     const double rest = n->flops_per_board - tower;
     const double pad_ch = ((double)g.Cp / C) * ((double)g.Cp / C);
-    if (n->f16) return 3.0 * (tower * (256.0 / (6.0 * cells)) * (5.0 / 6.0) * pad_ch + rest);
+    const int wg_rows = v->rw * 32 * v->mt, tb = wg_rows / g.cells;
+    const bool sk = v->game == 0 && v->pf == 0 && ((v->mt == 2 && v->rw == 4) || (v->mt == 4 && v->rw == 2 && v->cw == v->nt));
+    const bool tile16 = v->game == 2 && v->pf == 0 && v->cw == v->nt && v->rw == 1 && v->mt == 3 && v->nt >= 3;
+    const double rows = tile16 ? cells * tb : (double)wg_rows;         // GEMM rows the workgroup computes
+    if (boards_per_wg) *boards_per_wg = tb;
+    return tower * (rows / cells) * (sk ? 5.0 / 6.0 : 1.0) * pad_ch + rest * tb;
+}
+double resnet_exec_flops_per_board(const ResNetDev *n, int game, int max_leaves) {
+    if (!n) return 0.0;
+    if (n->f16) return resnet16_wg_flops(n->f16, n->flops_per_board) / 6.0;
     const Variant *v = pick_variant(n, game, max_leaves);
     if (!v) return 0.0;
-    const int wg_rows = v->rw * 32 * v->mt, tb = wg_rows / g.cells;
-    const bool sk = game == 0 && v->pf == 0 && ((v->mt == 2 && v->rw == 4) || (v->mt == 4 && v->rw == 2 && v->cw == v->nt));
-    const bool tile16 = game == 2 && v->pf == 0 && v->cw == v->nt && v->rw == 1 && v->mt == 3 && v->nt >= 3;
-    const double rows = tile16 ? cells : (double)wg_rows / tb;
-    return tower * (rows / cells) * (sk ? 5.0 / 6.0 : 1.0) * pad_ch + rest;
+    int tb = 1;
+    const double f = variant_wg_flops(n, v, &tb);
+    return f / tb;
+}
+// executed matrix-pipe FLOP summed on the device by every launch since the last reset (exact per workgroup)
+double resnet_exec_flops_total(const ResNetDev *n, bool reset) {
+    if (!n || !n->d_flop_acc) return 0.0;
+    double h = 0.0;
+    (void)hipMemcpy(&h, n->d_flop_acc, sizeof h, hipMemcpyDeviceToHost);
+    if (reset) (void)hipMemset(n->d_flop_acc, 0, sizeof(double));
+    return h;
 }
 
 // AZSP_RESNET_VARIANT, resolved once per network
@@ -381,11 +399,12 @@ bool resnet_has_fused(const ResNetDev *n, int game, int max_leaves, int tab_lds)
 }
 
 static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
-                         int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, const FusedArgs *fused);
+                         int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, const FusedArgs *fused,
+                         bool by_count = false);
 
 void resnet_forward(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
-                    int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s) {
-    forward_impl(n, game, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s, nullptr);
+                    int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, bool by_count) {
+    forward_impl(n, game, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s, nullptr, by_count);
 }
 
 // One FUSED round of a slot group: evaluates the leaves listed in leaf_slot[0 .. *n_leaf) and carries those games on
@@ -402,8 +421,13 @@ void resnet_forward_fused(ResNetDev *n, int game, const View &view, const u64 *l
 }
 
 static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
-                         int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, const FusedArgs *fused) {
-    if (n->f16) { resnet16_forward(n->f16, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s); return; }
+                         int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, const FusedArgs *fused,
+                         bool by_count) {
+    if (n->f16) {
+        resnet16_forward(n->f16, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s, by_count,
+                         n->d_flop_acc, resnet16_wg_flops(n->f16, n->flops_per_board));
+        return;
+    }
     const Variant *v = pick_variant(n, game, max_leaves);
     if (!v) return;                        // resnet_create refused every geometry without a variant
     FwdArgs a;
@@ -422,10 +446,32 @@ static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_str
     P.dbg = nullptr;
     P.perm = n->d_perm ? n->d_perm + v->perm_offset : nullptr;
     P.conv_w4 = n->has_w4 ? d + n->o_conv_w4 : nullptr;
+    P.flop_acc = n->d_flop_acc;
+    P.wg_flops = variant_wg_flops(n, v, nullptr);
     a.mine = leaf0; a.theirs = leaf0 + n->g_words; a.bstride = board_stride; a.leaf_slot = leaf_slot; a.n_leaf = n_leaf; a.max_leaves = max_leaves;
     a.out_p = out_p; a.out_v = out_v; a.p_stride = p_stride; a.v_stride = v_stride; a.s = s;
-    if (fused) fused_launcher(n, game, max_leaves)(a);
-    else v->launch(a);
+    if (fused) { fused_launcher(n, game, max_leaves)(a); return; }
+    if (!by_count || n->forced_variant >= 0) { v->launch(a); return; }
+    // by_count (evaluation cache): the list's length is known only on the device and varies from 1 to max_leaves.  Every
+    // variant of this network whose range of lengths (prev, max_boards] starts below max_leaves is enqueued, gated to that
+    // range: one of them does the work, the others return at once (a few microseconds of stream time each).
+    // (tuning knob AZSP_RESNET_GATES="a,b": upper ends of the first two ranges, multiples of 16; the variants return the same bits)
+    static const int gate_env[2] = {[] { const char *x = getenv("AZSP_RESNET_GATES"); return x ? atoi(x) / 16 * 16 : -1; }(),
+                                    [] { const char *x = getenv("AZSP_RESNET_GATES"); const char *c = x ? strchr(x, ',') : nullptr; return c ? atoi(c + 1) / 16 * 16 : -1; }()};
+    int prev = 0, k = 0;
+    for (const Variant &w : VARIANTS) {
+        if (w.game != game || w.nt != n->g.NT) continue;
+        if (prev >= max_leaves) break;
+        int hi = w.max_boards;
+        if (hi != INT_MAX && k < 2 && gate_env[k] >= 0) hi = gate_env[k];
+        ++k;
+        if (hi <= prev) continue;                        // an empty range: this variant is never the one
+        P.perm = n->d_perm ? n->d_perm + w.perm_offset : nullptr;
+        P.wg_flops = variant_wg_flops(n, &w, nullptr);
+        a.gate = (prev / 16) | ((hi == INT_MAX ? 0 : hi / 16) << 16);
+        w.launch(a);
+        prev = hi;
+    }
 }
 
 }  // namespace azsp

@@ -49,6 +49,9 @@ struct Net16Params {
     int conv_w_stride /* in h8 */, conv_b_stride, blocks;
     const int32_t *perm;               // [256] GEMM row -> board-cell row for this wave grid (tap skipping)
     unsigned long long *dbg;           // phase timestamps of the ABL = 8 diagnostic instantiation, else nullptr
+    double *flop_acc;                  // device accumulator of executed matrix-pipe FLOP, or nullptr
+    double wg_flops;                   // fp16 MFMA FLOP one workgroup executes (resnet16_wg_flops)
+    int gate;                          // launch gate as in the fp32 kernel: (lo / 16) | (hi / 16) << 16, 0 = none
 };
 // phase timestamp (100 MHz clock) of wave 0 of each workgroup; compiled only into the ABL & 8 diagnostic build
 #define STAMP16(k) do { if constexpr ((ABL & 8) != 0) { if (tid == 0) P.dbg[(size_t)blockIdx.x * 64 + (k)] = wall_clock64(); } } while (0)
@@ -306,6 +309,12 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     const int n_leaf = *n_leaf_p;
     const int board0 = blockIdx.x * TB;
     if (board0 >= n_leaf) return;
+    {   // launch gate: run only for list lengths in (lo, hi] (see the fp32 kernel)
+        const int lo = (P.gate & 0xffff) * 16, hi = (int)((unsigned)P.gate >> 16) * 16;
+        if (n_leaf <= lo || (hi != 0 && n_leaf > hi)) return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.flop_acc != nullptr)
+        atomicAdd(P.flop_acc, (double)((n_leaf + TB - 1) / TB) * P.wg_flops);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r32 = lane & 31;
     const int wr = wave / CT, wc = wave % CT;
     STAMP16(0);
@@ -733,14 +742,25 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, i
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done.fetch_or(bit, std::memory_order_release);
     }
-    const int grid = (max_leaves + TB - 1) / TB;
+    const int gate_hi = (int)((unsigned)P.gate >> 16) * 16;
+    const int cap = gate_hi != 0 && gate_hi < max_leaves ? gate_hi : max_leaves;
+    const int grid = (cap + TB - 1) / TB;
     Net16Params Q = P;
     Q.perm = P.perm + (size_t)(WR == 1 ? 0 : WR == 2 ? 1 : WR == 4 ? 2 : 3) * F16_ROWS;      // row order of this wave grid
     hipLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR, ABL>), dim3(grid), dim3(64 * WAVES), lds, s, Q, mine, theirs, bstride, leaf_slot, n_leaf, out_p, out_v, p_stride, v_stride);
 }
 
+// Every workgroup of this kernel holds 6 boards (252 of 256 GEMM rows) in the tap-skipping row order and issues three fp16
+// MFMAs (hi*hi, hi*lo, lo*hi) per fp32 multiply-add of the tower.
+double resnet16_wg_flops(const ResNet16Dev *n, double flops_per_board) {
+    const double C = n->C, cells = n->cells, CP = 32.0 * n->CT;
+    const double tower = 2.0 * cells * 2.0 * n->blocks * C * C * 9;
+    return 3.0 * (tower * (256.0 / cells) * (5.0 / 6.0) * (CP / C) * (CP / C) + (flops_per_board - tower) * 6.0);
+}
+
 void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32_t *leaf_slot, const int32_t *n_leaf,
-                      int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s) {
+                      int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, bool by_count,
+                      double *flop_acc, double wg_flops) {
     const u64 *mine = leaf0, *theirs = leaf0 + Connect4::W;
     Net16Params P;
     unsigned char *d = n->d_blob;
@@ -754,11 +774,17 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
     P.conv_w_stride = (int)n->conv_w_stride; P.conv_b_stride = (int)n->conv_b_stride; P.blocks = n->blocks;
     P.perm = n->d_perm;
     P.dbg = nullptr;
+    P.flop_acc = flop_acc;
+    P.wg_flops = wg_flops;
+    P.gate = 0;
     // wave grid WR x CT over the 256-row x C tile (tuning knob AZSP_F16_WR; results do not depend on it)
     static const int wr_env = [] { const char *e = getenv("AZSP_F16_WR"); return e ? atoi(e) : 0; }();
 #define L16(CTV, WRV) launch16<CTV, WRV>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s)
     switch (n->CT) {
-        case 1: if (wr_env == 8 || (!wr_env && max_leaves <= 768)) L16(1, 8); else L16(1, 4); break;
+        case 1:
+            if (by_count && !wr_env && max_leaves > 768) { P.gate = (768 / 16) << 16; L16(1, 8); P.gate = 768 / 16; L16(1, 4); P.gate = 0; break; }
+            if (wr_env == 8 || (!wr_env && max_leaves <= 768)) L16(1, 8); else L16(1, 4);
+            break;
         case 2: {
             bool print = false;
             if (resnet_trace_wanted(&print)) {     // diagnostic instantiation with the fp32 kernel's stamps: phase times, in-kernel clock
@@ -789,6 +815,8 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
                 break;
             }
 #endif
+            // by_count (evaluation cache): both wave grids enqueued, each gated to its range of list lengths
+            if (by_count && !wr_env && max_leaves > 768) { P.gate = (768 / 16) << 16; L16(2, 4); P.gate = 768 / 16; L16(2, 2); P.gate = 0; break; }
             if (wr_env == 4 || (!wr_env && max_leaves <= 768)) L16(2, 4); else L16(2, 2);   // small batch: more waves per board
             break;
         }

@@ -67,6 +67,7 @@ struct ResNetDev {
     bool has_w4 = false;
     int g_words = 1;              // 64-bit words per side of a position (game trait W)
     int forced_variant = -1;      // index into the variant table if AZSP_RESNET_VARIANT named one at creation, else -1
+    double *d_flop_acc = nullptr; // executed matrix-pipe FLOP of every launch since the last reset (both kernels add to it)
 };
 
 // FUSED rounds: what the inference kernel needs to carry its games on after evaluating them (advance_game)
@@ -84,6 +85,8 @@ struct NetParams {
     const int32_t *perm;          // [256] GEMM row -> board-cell row of the tap-skipping row order (see build_row_order)
     const float *conv_w4;         // conv weights as [tap][s / 4][column tile][lane][4 k-steps] (one 16-byte load per lane
                                   // feeds four k-steps of a wave that owns ONE column tile), else nullptr
+    double *flop_acc;             // device accumulator of EXECUTED matrix-pipe FLOP (one atomic per launch), or nullptr
+    double wg_flops;              // what one workgroup of this variant executes (resnet_exec_flops_per_board x boards per workgroup)
 };
 // phase timestamp of wave 0 of each workgroup, 100 MHz constant clock; compiled only into the TR = true
 // diagnostic instantiation (AZSP_RESNET_TRACE), the product kernels carry no stamp code
@@ -563,6 +566,15 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     const int n_leaf = *n_leaf_p;
     const int board0 = blockIdx.x * TB;
     if (board0 >= n_leaf) return;
+    if constexpr (!FUSED) {
+        // launch gate (FwdArgs::gate): with the evaluation cache the list's length is only known on the device and varies
+        // from 1 to the group's size, so the host enqueues every variant of the network and each runs only for lengths in
+        // its own range (lo, hi], in units of 16 boards; 0 = no gate
+        const int lo = (F & 0xffff) * 16, hi = (int)((unsigned)F >> 16) * 16;
+        if (n_leaf <= lo || (hi != 0 && n_leaf > hi)) return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.flop_acc != nullptr)       // the workgroups that get past the two returns above
+        atomicAdd(P.flop_acc, (double)((n_leaf + TB - 1) / TB) * P.wg_flops);
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = (tid >> 6) / CW, wc = (tid >> 6) % CW;    // row group, column group
     const int col0 = wc * NTW * 32;
@@ -1222,6 +1234,7 @@ struct FwdArgs {
     int p_stride, v_stride;
     hipStream_t s;
     const FusedArgs *fused;                 // FUSED variants only, else nullptr
+    int gate = 0;                           // (lo / 16) | (hi / 16) << 16: run only for list lengths in (lo, hi]; 0 = always
 };
 
 // tracing state lives in azsp_resnet.hip (one copy for all kernel translation units)
@@ -1265,13 +1278,15 @@ static void launch_forward(const FwdArgs &a) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done.fetch_or(bit, std::memory_order_release);
     }
-    const int grid = (a.max_leaves + TB - 1) / TB;
+    const int gate_hi = (int)((unsigned)a.gate >> 16) * 16;
+    const int cap = gate_hi != 0 && gate_hi < a.max_leaves ? gate_hi : a.max_leaves;      // longest list this launch can meet
+    const int grid = (cap + TB - 1) / TB;
     if constexpr (TRACEABLE) {
         bool print = false;
         if (resnet_trace_wanted(&print)) {
             trace_forward(a.P, grid, [&](const NetParams &Q) {
                 hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW, true>), dim3(grid), dim3(64 * RW * CW), lds, a.s, Q,
-                                   a.mine, a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, a.p_stride, a.v_stride, 0); }, a.s, print);
+                                   a.mine, a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, a.p_stride, a.v_stride, a.gate); }, a.s, print);
             return;
         }
     }
@@ -1280,7 +1295,7 @@ static void launch_forward(const FwdArgs &a) {
                            a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, a.p_stride, a.v_stride, *a.fused);
     } else {
         hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW>), dim3(grid), dim3(64 * RW * CW), lds, a.s, a.P, a.mine, a.theirs,
-                           a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, a.p_stride, a.v_stride, 0);
+                           a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, a.p_stride, a.v_stride, a.gate);
     }
 }
 

@@ -335,12 +335,13 @@ def main() -> None:
         overlap = st["infer_ms"] / union_ms if union_ms > 0 else 1.0
         peak = PEAK_TFLOPS[precision]
         boards = st["infer_boards"]                  # positions the kernel evaluated (== evals unless the evaluation cache is on)
-        # EXECUTED matrix-pipe FLOP per board of the kernel variant in use (libazsp: padding rows of the workgroup tile
-        # included, statically skipped off-board taps excluded, x 3 for f16x2's hi*hi + hi*lo + lo*hi); a full last
-        # workgroup is assumed for every launch (214 workgroups per launch at the headline: < 0.5 %)
-        efpb = st["infer_exec_flops_per_board"]
+        # EXECUTED matrix-pipe FLOP, summed on the device: every inference launch adds (workgroups that had boards) x (what
+        # one workgroup of that kernel variant executes: the padding rows of its tile included, statically skipped
+        # off-board taps excluded, x 3 for f16x2's hi*hi + hi*lo + lo*hi)
+        exec_flops = st["infer_exec_flops"]
+        efpb = exec_flops / max(boards, 1)
         tf = lambda flop, ms: flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0      # noqa: E731
-        achieved = tf(efpb * boards, union_ms)
+        achieved = tf(exec_flops, union_ms)
         algorithmic = tf(fpb * boards, union_ms)
         return {
             "value": episodes / dt, "unit": "episodes/s", "ms_per_step": 1e3 * dt / max(args.steps, 1), "dtype": DTYPE[precision],
@@ -356,12 +357,12 @@ def main() -> None:
                          "frac": achieved / peak, "traffic": pmc_traffic(KERNEL[precision]),
                          "executed_flops_per_board": efpb, "flops_per_board": fpb,
                          "algorithmic_achieved": algorithmic, "algorithmic_frac": algorithmic / peak,
-                         "frac_over_wall": tf(efpb * boards, dt * 1e3) / peak,
+                         "frac_over_wall": tf(exec_flops, dt * 1e3) / peak,
                          "boards_per_launch": boards / launches, "avg_launch_ms": avg_ms, "launches": launches,
                          "concurrent_launches": overlap, "busy_ms": union_ms,
                          # the same without the overlap factor: one launch's executed flops / its own duration (the
                          # launches of the slot groups share the machine: a per-launch share, not the machine's rate)
-                         "per_launch_frac": tf(efpb * boards / launches, avg_ms) / peak if avg_ms > 0 else None,
+                         "per_launch_frac": tf(exec_flops / launches, avg_ms) / peak if avg_ms > 0 else None,
                          "infer_share_of_wall": union_ms * 1e-3 / dt if dt > 0 else None},
             "tree": tree_report(st, dt, n_act),
         }

@@ -113,7 +113,7 @@ typedef struct azsp_config {
                                 (azsp_play_begin/commit) lets one shard emit more than its own n_slots.    */
     int32_t  search_rules;   /* AZSP_RULES_*                                                           */
     int32_t  eval_cache_entries; /* AZSP_FLAG_EVAL_CACHE: table entries (64 B each, rounded up to a power of two,
-                                    at most 2^26); 0 = automatic (16 * n_slots * (n_sims + 1))              */
+                                    at most 2^26); 0 = automatic (64 * n_slots * (n_sims + 1))              */
 } azsp_config;
 
 /* Host evaluator: boards int8[n][cells] (canonical) -> p float32[n][n_actions], v float32[n].
@@ -150,10 +150,13 @@ typedef struct azsp_stats {
     uint64_t evals_executed;           /* positions actually evaluated (== evals without AZSP_FLAG_EVAL_CACHE; with it
                                           the count can vary by a few between identical runs: two slot groups that
                                           meet the same new position in the same search both evaluate it) */
-    double   infer_exec_flops_per_board;   /* matrix-pipe FLOP the selected inference kernel variant EXECUTES per board
+    double   infer_exec_flops_per_board;   /* matrix-pipe FLOP the inference kernel variant of a full-size launch EXECUTES per board
                                           slot of a full workgroup: padding rows included, statically skipped
                                           off-board taps excluded, x 3 for the split-fp16 kernel (hi*hi, hi*lo, lo*hi) */
     uint64_t eval_cache_entries;       /* table size in use (0 = cache off)                              */
+    double   infer_exec_flops;         /* matrix-pipe FLOP executed by all inference launches, summed ON THE DEVICE: every
+                                          launch adds (workgroups that had boards) x (FLOP one workgroup of that variant
+                                          executes) -- exact per workgroup, whichever variant ran                      */
 } azsp_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
