@@ -85,6 +85,7 @@ struct azsp_engine {
     hipStream_t stream = nullptr;                 // main stream (group 0 runs on it too)
     hipStream_t gstream[MAX_GROUPS] = {};         // gstream[0] == stream
     hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
+    hipEvent_t ev_tree[MAX_GROUPS] = {};          // evaluation cache with several slot groups: the ring of tree steps (search_enqueue)
     int n_groups = 1;
     View v{};
     std::vector<void *> allocs;
@@ -302,12 +303,28 @@ static int search_enqueue(azsp_engine *e, int n_act) {
         HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
         for (int k = 1; k < G; ++k) HIP_TRY(hipStreamWaitEvent(e->gstream[k], e->ev_fork, 0));
     }
+    // Evaluation cache with several slot groups: group k may use an entry that a LOWER group claimed during this very
+    // search (ent_claim), so the tree steps of the groups run as a ring -- step t of group k after step t of group k - 1,
+    // step t + 1 of group 0 after step t of the last group.  A lower group j is then never more than one step ahead of k:
+    // every claim of j that step t of k can see was made in j's steps <= t, their rows are written by j's inference
+    // launches up to the one after its step t, and k reads them in its step t + 1, which starts after j's step t + 1,
+    // i.e. after that launch (stream order on j).  Tree launches still overlap the other groups' inference launches.
+    const bool ring = cache && G > 1;
+    auto ring_wait = [&](int k, bool first_step) -> int {           // before tree step t of group k
+        if (!ring) return 0;
+        if (k > 0) HIP_TRY(hipStreamWaitEvent(e->gstream[k], e->ev_tree[k - 1], 0));
+        else if (!first_step) HIP_TRY(hipStreamWaitEvent(e->gstream[0], e->ev_tree[G - 1], 0));
+        return 0;
+    };
+    auto ring_done = [&](int k) -> int { if (ring) HIP_TRY(hipEventRecord(e->ev_tree[k], e->gstream[k])); return 0; };
     for (int k = 0; k < G; ++k) {
         hipStream_t st = e->gstream[k];
         if (cache) {
             // the roots join the list from k_root_prepare (entries, claimed once per position): zero its counters first
             HIP_TRY(hipMemsetAsync(gv[k].nl, 0, 4 * sizeof(int32_t), st));
+            { int rc = ring_wait(k, true); if (rc) return rc; }
             launch_root_prepare(game, gv[k], st);
+            { int rc = ring_done(k); if (rc) return rc; }
         } else {
             launch_root_prepare(game, gv[k], st);
             launch_compact(gv[k], st);
@@ -355,9 +372,11 @@ static int search_enqueue(azsp_engine *e, int n_act) {
                 View w = gv[k];
                 w.nl = e->v.n_leaf + 4 * k + ((s + 1) & 1);
                 w.nl_other = e->v.n_leaf + 4 * k + (s & 1);
+                { int rc = ring_wait(k, false); if (rc) return rc; }
                 EventPair *p = ev_begin(e, EV_SELECT, st);
                 launch_expand_select(game, w, st);
                 ev_end(p, st);
+                { int rc = ring_done(k); if (rc) return rc; }
                 e->stats.select_launches++;
                 int rc = evaluate_leaves(e, w, st);
                 if (rc) return rc;
@@ -381,9 +400,11 @@ static int search_enqueue(azsp_engine *e, int n_act) {
             View w = gv[k];
             w.nl = e->v.n_leaf + 4 * k + (descents & 1);
             w.nl_other = e->v.n_leaf + 4 * k + ((descents + 1) & 1);
+            { int rc = ring_wait(k, false); if (rc) return rc; }
             EventPair *p = ev_begin(e, EV_EXPAND, e->gstream[k]);
             launch_expand(game, w, e->gstream[k]);
             ev_end(p, e->gstream[k]);
+            { int rc = ring_done(k); if (rc) return rc; }
             e->stats.expand_launches++;
         }
     for (int k = 1; k < G; ++k) {
@@ -477,6 +498,7 @@ void azsp_destroy(azsp_engine *e) {
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     for (int k = 1; k < MAX_GROUPS; ++k) {
         if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
+        if (e->ev_tree[k]) (void)hipEventDestroy(e->ev_tree[k]);
         if (e->gstream[k]) (void)hipStreamDestroy(e->gstream[k]);
     }
     if (e->net) resnet_destroy(e->net);
@@ -519,12 +541,17 @@ static int create_impl(azsp_engine *e) {
     // read where stream order guarantees it, azsp_internal.h), and games in lock-step meet the same new positions in the
     // same round -- measured at the headline: 2.94 x fewer evaluations with one group, 2.31 x with two, 2.16 x with three.
     // With a third of the evaluations a round no longer fills the machine twice over, so one group's launch leaves little
-    // for a second group to overlap with: 3981 / 3595 / 3387 episodes/s (fp32), 7738 / 8070 / 8055 (f16x2).
-    if (c.n_groups <= 0 && (c.flags & AZSP_FLAG_EVAL_CACHE)) e->n_groups = (c.flags & AZSP_FLAG_F16_SPLIT) && c.n_slots >= 1024 ? 2 : 1;
+    // for a second group to overlap with: 3981 / 3595 / 3387 episodes/s (fp32), 7738 / 8070 / 8055 (f16x2).  With the ring of
+    // tree steps (search_enqueue: a group may use what a lower group claimed in the same search) several groups reach
+    // 2.87 x / 2.85 x, but no more episodes/s than one (4005 / 4005 / 3792 fp32, 7720 / 7880 / 7554 f16x2): a round is one
+    // workgroup's latency either way.  One group unless the caller asks for more.
+    if (c.n_groups <= 0 && (c.flags & AZSP_FLAG_EVAL_CACHE)) e->n_groups = 1;
     for (int k = 1; k < e->n_groups; ++k) {
         HIP_TRY(hipStreamCreateWithFlags(&e->gstream[k], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
     }
+    if (c.flags & AZSP_FLAG_EVAL_CACHE)
+        for (int k = 0; k < e->n_groups; ++k) HIP_TRY(hipEventCreateWithFlags(&e->ev_tree[k], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     View &v = e->v;
     const int N = c.n_slots, A = gi.A, S = c.n_sims, W = gi.W, AP = gi.AP;

@@ -162,13 +162,13 @@ struct Gomoku9 {
     static AZ_HD bool pos_key(const B &, const B &, u64 &key) { key = 0; return false; }     // 3^81 positions: no 64-bit key
     static AZ_HD bool legal(const B &m, const B &t, int a) {
         const int bit = bit_of(a / COLS, a % COLS);
-        return !(board_bit(m, bit) | board_bit(t, bit));
+        return !(board_bit(m, bit) || board_bit(t, bit));
     }
     static AZ_HD void play(const B &m, const B &t, int a, B &nm, B &nt) {
         nm = t;
         nt = m;
         const int bit = bit_of(a / COLS, a % COLS);
-        if (!(board_bit(m, bit) | board_bit(t, bit))) board_set(nt, bit);
+        if (!(board_bit(m, bit) || board_bit(t, bit))) board_set(nt, bit);
     }
     static AZ_HD B shr(const B &b, int s) {          // 128-bit logical shift right, 0 < s < 64
         B r;

@@ -76,10 +76,12 @@ struct TreeGeo {
 // The claiming game ("owner") stores the position and puts the ENTRY on its group's leaf list; the inference kernel
 // reads the position from the entry and writes (p, v) into it; every game -- owner or not -- keeps the entry's index in
 // its slot record and reads the row from there when it expands the leaf in its group's next tree launch.  Ordering
-// needs nothing beyond streams: a row is read only (a) from an entry claimed by the reader's own slot group (its
-// inference launch sits between the claim and the read on the group's stream) or (b) from an entry claimed in an earlier
-// search (all group streams join the main stream at the end of every search).  A key claimed by ANOTHER group during the
-// current search is not usable yet: the game falls back to its private entry (a duplicate evaluation, same bits).
+// needs nothing beyond streams and events: a row is read only (a) from an entry claimed by the reader's own slot group
+// (its inference launch sits between the claim and the read on the group's stream), (b) from an entry claimed in an
+// earlier search (all group streams join the main stream at the end of every search), or (c) from an entry a LOWER
+// group claimed during this search -- the groups' tree steps run as a ring (search_enqueue), which puts that group's
+// inference launch before the read.  A key claimed by a HIGHER group during the current search is not usable yet: the
+// game falls back to its private entry (a duplicate evaluation, same bits).
 struct alignas(64) EvalEnt { u64 key; u64 mine, theirs, pad; float row[8]; };   // row = p[0..A), value at [7]  (AP == 8 games)
 constexpr int EVAL_PROBES = 16;
 constexpr u64 EVAL_POS_MASK = (1ull << 49) - 1;

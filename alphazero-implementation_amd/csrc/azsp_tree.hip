@@ -153,12 +153,14 @@ __global__ __launch_bounds__(64) void k_select(View v) {
     const int gl = blockIdx.x * GPW + grp;
     const bool live = gl < v.n_act;
     const int g = live ? v.lo + gl : v.lo;
+    typename G::B cur_m = board_zero<G::W>(), cur_t = board_zero<G::W>();
+    if (live) { cur_m = board_load<G::W>(v.cur_mine, g); cur_t = board_load<G::W>(v.cur_theirs, g); }
     SlotRegs<G> st;
     slot_load<G>(v, g, lane, live, st);
     __syncthreads();
     int leaf_id;
     bool leaf_add;                     // (the slot-ordered four-launch rounds run without the evaluation cache: v.ent == nullptr)
-    select_game<G, R>(v, g, lane, grp, live, st, s_path, tb, leaf_id, leaf_add);
+    select_game<G, R>(v, g, lane, grp, live, st, s_path, tb, cur_m, cur_t, leaf_id, leaf_add);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -266,6 +268,9 @@ __global__ __launch_bounds__(64) void k_expand_select(View v) {
     const int gl = blockIdx.x * GPW + grp;
     const bool in = gl < v.n_act;
     const int g = in ? v.lo + gl : v.lo;
+    // the game's current position is requested together with its slot record (the descent below starts from it)
+    typename G::B cur_m = board_zero<G::W>(), cur_t = board_zero<G::W>();
+    if (in) { cur_m = board_load<G::W>(v.cur_mine, g); cur_t = board_load<G::W>(v.cur_theirs, g); }
     SlotRegs<G> st;
     slot_load<G>(v, g, lane, in, st);
     const bool pend = in && st.pending != 0;
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(64) void k_expand_select(View v) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     int leaf_id;
     bool leaf_add;
-    const int term = select_game<G, R>(v, g, lane, grp, in, st, s_path, tb, leaf_id, leaf_add);
+    const int term = select_game<G, R>(v, g, lane, grp, in, st, s_path, tb, cur_m, cur_t, leaf_id, leaf_add);
     const bool need = in && term == TERM_NONE && lane == 0;
     append_leaves(v, need, need && leaf_add, leaf_id, v.leaf_slot, v.nl);
 }

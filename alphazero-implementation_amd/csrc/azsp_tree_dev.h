@@ -160,9 +160,10 @@ __device__ __forceinline__ int ent_claim(const View &v, int g, const typename G:
             const u64 old = atomicCAS(kp, 0ull, (unsigned long long)word);
             if (old == 0) { id = v.n_slots + (int)h; break; }                   // claimed
             if ((old & EVAL_POS_MASK) == pk) {
-                // the same position: usable if this group claimed it (its inference launch precedes our next read on the
-                // group's stream) or an earlier search did (all streams joined since); otherwise evaluate privately
-                if ((int)((old >> 49) & 7) == v.grp || (int)(old >> 52) != v.ent_epoch) { id = v.n_slots + (int)h; owner = false; }
+                // the same position: usable if this group or a LOWER one claimed it (own stream order; the ring of tree steps
+                // in search_enqueue puts the lower group's inference launch before our next read) or an earlier search did
+                // (all streams joined since); a HIGHER group's claim of this search is not: evaluate privately
+                if ((int)((old >> 49) & 7) <= v.grp || (int)(old >> 52) != v.ent_epoch) { id = v.n_slots + (int)h; owner = false; }
                 break;
             }
         }
@@ -296,9 +297,12 @@ __device__ __forceinline__ void expand_game(const View &v, int g, int lane, int 
 // instead of by the stable k_compact pass that the host-callback evaluator needs.
 // leaf_id / leaf_add (meaningful on lane 0 of a game whose descent ended on a non-terminal leaf): what goes on the leaf
 // list -- the slot itself, or with the evaluation cache the entry to evaluate, and only if this game claimed it
+// cur_m / cur_t: the game's current position (the root's), loaded by the caller -- together with the slot record, so
+// that the descent does not start with a round trip of its own
 template <class G, int R>
 __device__ __forceinline__ int select_game(const View &v, int g, int lane, int grp, bool live, SlotRegs<G> &st, int *s_path,
-                                            const Tabs &tb, int &leaf_id, bool &leaf_add) {
+                                            const Tabs &tb, const typename G::B &cur_m, const typename G::B &cur_t,
+                                            int &leaf_id, bool &leaf_add) {
     leaf_id = g;
     leaf_add = true;
     using WT = typename std::conditional<R == 0, float, double>::type;
@@ -316,8 +320,8 @@ __device__ __forceinline__ int select_game(const View &v, int g, int lane, int g
     int kid = 0, n_root = 0;                           // 1 + block of the node's children (0 = unexpanded)
     typename G::B bm = board_zero<G::W>(), bt = board_zero<G::W>();
     if (live) {
-        bm = board_load<G::W>(v.cur_mine, g);
-        bt = board_load<G::W>(v.cur_theirs, g);
+        bm = cur_m;
+        bt = cur_t;
         if (root == 0) { kid = st.root_kid; n_root = st.root_n; }
         else { const NodeChunk c = *node_chunk<G>(v, g, root); kid = c.kid; n_root = c.n; }
     }
@@ -455,8 +459,6 @@ __device__ __forceinline__ int select_game(const View &v, int g, int lane, int g
             h->pending = 0;
             h->root_n = st.root_n;
             h->root_w = st.root_w;
-            atomicAdd(&v.counters[1], 1ull);
-            atomicAdd(&v.counters[2], (unsigned long long)L);
         }
     } else if (live) {
         int32_t *path = reinterpret_cast<int32_t *>(slot_ptr(v, g) + T::PATH_CHUNK * 16);
@@ -478,9 +480,20 @@ __device__ __forceinline__ int select_game(const View &v, int g, int lane, int g
                 }
             }
             slot_store_leaf<G>(v, g, bm, bt);
-            atomicAdd(&v.counters[2], (unsigned long long)L);
         }
         if constexpr (G::W == 1) st.eval_ent = __shfl(leaf_id, 0, LPG);
+    }
+    // statistics: ONE atomic per wavefront and counter (one per game made 4096 same-address atomics per launch)
+    {
+        const bool l0 = live && lane == 0;
+        const unsigned long long terms = __ballot(l0 && term != TERM_NONE);
+        int lsum = l0 ? L : 0;
+#pragma unroll
+        for (int m = LPG; m < 64; m <<= 1) lsum += __shfl_xor(lsum, m, 64);
+        if ((threadIdx.x & 63) == 0) {
+            if (lsum) atomicAdd(&v.counters[2], (unsigned long long)lsum);
+            if (terms) atomicAdd(&v.counters[1], (unsigned long long)__popcll(terms));
+        }
     }
     return term;
 }
@@ -525,11 +538,13 @@ __device__ __forceinline__ void advance_game(const View &v, int g, int lane, int
     if (live && lane == 0) slot_store_head<G>(v, g, st);
     bool again = live && st.sims_done < v.n_sims;
     bool found = false;
+    typename G::B cur_m = board_zero<G::W>(), cur_t = board_zero<G::W>();
+    if (live) { cur_m = board_load<G::W>(v.cur_mine, g); cur_t = board_load<G::W>(v.cur_theirs, g); }
     while (__any(again)) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // this wave's stores before its own next loads
         int leaf_id;
         bool leaf_add;
-        const int term = select_game<G, R>(v, g, lane, grp, again, st, s_path, tb, leaf_id, leaf_add);     // (FUSED rounds run without the evaluation cache)
+        const int term = select_game<G, R>(v, g, lane, grp, again, st, s_path, tb, cur_m, cur_t, leaf_id, leaf_add);     // (FUSED rounds run without the evaluation cache)
         if (again) {
             if (term != TERM_NONE) {
                 st.sims_done += 1;
