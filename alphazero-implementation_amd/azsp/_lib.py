@@ -25,7 +25,8 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("game", C.c_int32), ("n_slots", C.c_int32), ("n_sims", C.c_int32),
                 ("device", C.c_int32), ("res_blocks", C.c_int32), ("channels", C.c_int32), ("flags", C.c_uint32),
                 ("hash_salt", C.c_uint64), ("n_groups", C.c_int32), ("arena_episodes", C.c_int32),
-                ("search_rules", C.c_int32), ("eval_cache_entries", C.c_int32)]
+                ("search_rules", C.c_int32), ("eval_cache_entries", C.c_int32), ("timing_sample", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class PlyResult(C.Structure):
@@ -41,7 +42,7 @@ class Stats(C.Structure):
                 ("play_ms", C.c_double), ("select_launches", C.c_uint64), ("expand_launches", C.c_uint64),
                 ("path_nodes", C.c_uint64), ("infer_union_ms", C.c_double), ("evals_executed", C.c_uint64),
                 ("infer_exec_flops_per_board", C.c_double), ("eval_cache_entries", C.c_uint64),
-                ("infer_exec_flops", C.c_double)]
+                ("infer_launches_timed", C.c_uint64), ("infer_exec_flops", C.c_double)]
 
 
 class SearchOptions(C.Structure):

@@ -31,7 +31,7 @@ class Engine:
     def __init__(self, game, n_slots: int, n_sims: int, *, device: int = 0, res_blocks: int = 0, channels: int = 0,
                  timing: bool = False, hash_salt: int = 0, n_groups: int = 0, f16_split: bool = False, arena_episodes: int = 0,
                  search_rules: int = L.RULES_SIMPLE, tree_reuse: bool = False, eval_cache: bool = False,
-                 eval_cache_entries: int = 0):
+                 eval_cache_entries: int = 0, timing_sample: int = 0):
         self.lib = L.load()
         self.game_id = game_id_of(game)
         r, c, a, mp = (C.c_int32() for _ in range(4))
@@ -46,7 +46,8 @@ class Engine:
                        self.channels,
                        (L.FLAG_TIMING if timing else 0) | (L.FLAG_F16_SPLIT if f16_split else 0)
                        | (L.FLAG_TREE_REUSE if tree_reuse else 0) | (L.FLAG_EVAL_CACHE if eval_cache else 0),
-                       int(hash_salt) & (2**64 - 1), int(n_groups), int(arena_episodes), int(search_rules), int(eval_cache_entries))
+                       int(hash_salt) & (2**64 - 1), int(n_groups), int(arena_episodes), int(search_rules), int(eval_cache_entries),
+                       int(timing_sample), 0)
         self.search_rules = int(search_rules)
         h = C.c_void_p()
         L.check(self.lib.azsp_create(C.byref(cfg), C.byref(h)))

@@ -23,11 +23,12 @@ class EpisodeGenerator:
                  n_groups: int = 0, f16_split: bool = False, sampling_plies: int | None = None,
                  dirichlet_alpha: float | None = None, dirichlet_eps: float = 0.25, c_init: float = 1.0,
                  c_base: float = 0.0, numpy1_value_sums: bool = False, tree_reuse: bool = False, eval_cache: bool = False,
-                 eval_cache_entries: int = 0):
+                 eval_cache_entries: int = 0, timing_sample: int = 0):
         self.game = game
         self.config = config
         self.device = device
         self.timing = timing
+        self.timing_sample = timing_sample    # timing=True: time only 8 of every 8 * timing_sample simulation rounds (0 / 1: all)
         # search options beyond the reference (None/off = reference behaviour): arg-max moves after
         # `sampling_plies` plies; gamma(alpha) root noise mixed in with weight `dirichlet_eps`, drawn per ply from
         # the global numpy RNG BEFORE the ply's uniforms (n_slots x n_actions values)
@@ -59,7 +60,8 @@ class EpisodeGenerator:
                                   res_blocks=blocks, channels=ch, timing=self.timing, hash_salt=salt,
                                   n_groups=self.n_groups, f16_split=self.f16_split,
                                   search_rules=2 if self.numpy1_value_sums else 0, tree_reuse=self.tree_reuse,
-                                  eval_cache=self.eval_cache, eval_cache_entries=self.eval_cache_entries)
+                                  eval_cache=self.eval_cache, eval_cache_entries=self.eval_cache_entries,
+                                  timing_sample=self.timing_sample)
             self._engine_key = key
         configure_engine_for_model(self._engine, model)
         return self._engine

@@ -117,6 +117,7 @@ struct azsp_engine {
     EvalEnt *d_ent = nullptr;
     size_t ent_table = 0;
     int ent_shift = 0, ent_epoch = 0;
+    bool timed_now = true;            // AZSP_FLAG_TIMING with timing_sample > 1: whether the round being enqueued is in a timed window
     int last_infer_cap = 0;           // board capacity of the most recent inference launch (selects the kernel variant)
     double *d_st_wd = nullptr, *d_st_rwd = nullptr;   // float64 root statistics staging
     double *d_sqrt = nullptr, *d_ctab = nullptr, *d_expl = nullptr;   // [n_sims + 2] exploration tables
@@ -159,6 +160,19 @@ static EventPair *ev_begin(azsp_engine *e, int kind, hipStream_t st) {
     return p;
 }
 static void ev_end(EventPair *p, hipStream_t st) { if (p) (void)hipEventRecord(p->b, st); }
+// a pair for a launch that records its own start / end (hipExtLaunchKernelGGL): nothing is enqueued here
+static EventPair *ev_pair(azsp_engine *e, int kind) {
+    if (!(e->cfg.flags & AZSP_FLAG_TIMING) || !e->timed_now) return nullptr;
+    if (kind == EV_INFER) e->stats.infer_launches_timed++;
+    if (e->ev_used == e->ev_pool.size()) {
+        EventPair p{};
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+        e->ev_pool.push_back(p);
+    }
+    EventPair *p = &e->ev_pool[e->ev_used++];
+    p->kind = kind;
+    return p;
+}
 
 static void ev_collect(azsp_engine *e) {       // call only after the streams have been synchronised
     // Inference launches of different slot groups overlap in time; besides the per-launch sum, keep
@@ -211,19 +225,19 @@ static int evaluate_leaves(azsp_engine *e, const View &v, hipStream_t st) {
             return 0;
         case AZSP_EVAL_RESNET: {
             if (!e->net || !e->net_loaded) return fail(AZSP_ERR_STATE, "ResNet evaluator selected but no weights loaded (azsp_load_resnet)");
-            EventPair *p = ev_begin(e, EV_INFER, st);
+            EventPair *p = ev_pair(e, EV_INFER);
+            hipEvent_t ea = p ? p->a : nullptr, eb = p ? p->b : nullptr;
             e->last_infer_cap = v.n_act;
             if (v.ent != nullptr) {
                 // evaluation cache: the list holds entries; positions are read from and rows written into them
                 float *row0 = v.ent[0].row;
                 resnet_forward(e->net, game, &v.ent[0].mine, (int)(sizeof(EvalEnt) / 8), v.leaf_slot + v.lo, v.nl, v.n_act, row0,
-                               (int)(sizeof(EvalEnt) / 4), row0 + 7, (int)(sizeof(EvalEnt) / 4), st, /*by_count=*/true);
+                               (int)(sizeof(EvalEnt) / 4), row0 + 7, (int)(sizeof(EvalEnt) / 4), st, /*by_count=*/true, ea, eb);
             } else {
                 // leaf positions sit in the slot records; outputs are indexed by slot, so groups never share rows
                 resnet_forward(e->net, game, reinterpret_cast<const u64 *>(v.slot + e->leaf_off), v.slot_bytes / 8, v.leaf_slot + v.lo, v.nl,
-                               v.n_act, v.eval_p, v.eval_pstride, v.eval_v, v.eval_vstride, st);
+                               v.n_act, v.eval_p, v.eval_pstride, v.eval_v, v.eval_vstride, st, false, ea, eb);
             }
-            ev_end(p, st);
             e->stats.infer_launches++;
             return 0;
         }
@@ -317,6 +331,12 @@ static int search_enqueue(azsp_engine *e, int n_act) {
         return 0;
     };
     auto ring_done = [&](int k) -> int { if (ring) HIP_TRY(hipEventRecord(e->ev_tree[k], e->gstream[k])); return 0; };
+    // AZSP_FLAG_TIMING with timing_sample = n > 1: events only in windows of 8 consecutive rounds out of every 8 n (the
+    // root stage counts as round 0): attaching timestamps to a dispatch costs a few microseconds of its own, which shows
+    // where a round is launch latency (evaluation cache, few games)
+    const int tsamp = e->cfg.timing_sample > 1 ? e->cfg.timing_sample : 1;
+    auto in_window = [&](int round) { return tsamp == 1 || (round % (8 * tsamp)) < 8; };
+    e->timed_now = in_window(0);
     for (int k = 0; k < G; ++k) {
         hipStream_t st = e->gstream[k];
         if (cache) {
@@ -336,20 +356,22 @@ static int search_enqueue(azsp_engine *e, int n_act) {
     if (fused_rounds) {
         for (int r = 0; r <= e->cfg.n_sims; ++r)
             for (int k = 0; k < G; ++k) {
+                e->timed_now = in_window(r);
                 hipStream_t st = e->gstream[k];
                 View w = gv[k];
                 int32_t *cnt = e->v.n_leaf + 4 * k;
                 int32_t *cur_list = (r & 1) ? e->v.leaf_slot2 : e->v.leaf_slot, *next_list = (r & 1) ? e->v.leaf_slot : e->v.leaf_slot2;
-                EventPair *p = ev_begin(e, EV_INFER, st);
+                EventPair *p = ev_pair(e, EV_INFER);
                 resnet_forward_fused(e->net, game, w, reinterpret_cast<const u64 *>(w.slot + e->leaf_off), w.slot_bytes / 8,
-                                     cur_list + w.lo, cnt + r % 3, next_list, cnt + (r + 1) % 3, cnt + (r + 2) % 3, w.n_act, st);
-                ev_end(p, st);
+                                     cur_list + w.lo, cnt + r % 3, next_list, cnt + (r + 1) % 3, cnt + (r + 2) % 3, w.n_act, st,
+                                     p ? p->a : nullptr, p ? p->b : nullptr);
                 e->stats.infer_launches++;
             }
         for (int k = 1; k < G; ++k) {
             HIP_TRY(hipEventRecord(e->ev_join[k], e->gstream[k]));
             HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join[k], 0));
         }
+        e->timed_now = true;
         e->v.lo = 0;
         e->v.grp = 0;
         e->v.n_act = n_act;
@@ -365,6 +387,7 @@ static int search_enqueue(azsp_engine *e, int n_act) {
     if (!fused)
         for (int k = 0; k < G; ++k) launch_expand(game, gv[k], e->gstream[k]);
     for (int s = 0; s < descents; ++s) {
+        e->timed_now = in_window(s + 1);
         for (int k = 0; k < G; ++k) {
             hipStream_t st = e->gstream[k];
             if (fused) {
@@ -373,9 +396,8 @@ static int search_enqueue(azsp_engine *e, int n_act) {
                 w.nl = e->v.n_leaf + 4 * k + ((s + 1) & 1);
                 w.nl_other = e->v.n_leaf + 4 * k + (s & 1);
                 { int rc = ring_wait(k, false); if (rc) return rc; }
-                EventPair *p = ev_begin(e, EV_SELECT, st);
-                launch_expand_select(game, w, st);
-                ev_end(p, st);
+                EventPair *p = ev_pair(e, EV_SELECT);
+                launch_expand_select(game, w, st, p ? p->a : nullptr, p ? p->b : nullptr);
                 { int rc = ring_done(k); if (rc) return rc; }
                 e->stats.select_launches++;
                 int rc = evaluate_leaves(e, w, st);
@@ -401,9 +423,8 @@ static int search_enqueue(azsp_engine *e, int n_act) {
             w.nl = e->v.n_leaf + 4 * k + (descents & 1);
             w.nl_other = e->v.n_leaf + 4 * k + ((descents + 1) & 1);
             { int rc = ring_wait(k, false); if (rc) return rc; }
-            EventPair *p = ev_begin(e, EV_EXPAND, e->gstream[k]);
-            launch_expand(game, w, e->gstream[k]);
-            ev_end(p, e->gstream[k]);
+            EventPair *p = ev_pair(e, EV_EXPAND);
+            launch_expand(game, w, e->gstream[k], p ? p->a : nullptr, p ? p->b : nullptr);
             { int rc = ring_done(k); if (rc) return rc; }
             e->stats.expand_launches++;
         }
@@ -411,6 +432,7 @@ static int search_enqueue(azsp_engine *e, int n_act) {
         HIP_TRY(hipEventRecord(e->ev_join[k], e->gstream[k]));
         HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join[k], 0));
     }
+    e->timed_now = true;
     e->v.lo = 0;
     e->v.grp = 0;
     e->v.n_act = n_act;

@@ -171,8 +171,8 @@ void launch_root_prepare(int game, const View &v, hipStream_t s);
 void launch_select(int game, const View &v, hipStream_t s);
 void launch_compact(const View &v, hipStream_t s);
 void launch_eval_hash(int game, const View &v, uint64_t salt, hipStream_t s);      // (rows into the cache entries when v.ent)
-void launch_expand(int game, const View &v, hipStream_t s);
-void launch_expand_select(int game, const View &v, hipStream_t s);      // expand of round r-1 fused with select of round r
+void launch_expand(int game, const View &v, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+void launch_expand_select(int game, const View &v, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);   // expand of round r-1 fused with select of round r
 void launch_leaf_cells(int game, const View &v, int8_t *dst, hipStream_t s);
 void launch_scatter_eval(int game, const View &v, const float *p_compact, const float *v_compact, hipStream_t s);   // host evaluator: compact order -> slot order
 void launch_finish(int game, const View &v, const double *uniforms, hipStream_t s);
@@ -199,14 +199,15 @@ size_t resnet_blob_floats(int game, int blocks, int channels);
 // by_count: pick the kernel variant by the list's length on the device (all variants enqueued, gated), not by max_leaves
 void resnet_forward(ResNetDev *, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot,
                     const int32_t *n_leaf, int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s,
-                    bool by_count = false);
+                    bool by_count = false, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// (ev_start / ev_stop: optional events that take the launch's own start / end timestamps from its dispatch packet)
 // (results of slot g: p at out_p + g * p_stride, value at out_v + g * v_stride -- strides in floats)
 // FUSED rounds (one-board Connect-4 kernels of the fp32 network, up to 32 games): one launch evaluates the listed leaves
 // AND carries those games on to their next leaf (azsp_tree_dev.h advance_game)
 bool resnet_has_fused(const ResNetDev *, int game, int max_leaves, int tab_lds);
 void resnet_forward_fused(ResNetDev *, int game, const View &view, const u64 *leaf0, int board_stride, const int32_t *leaf_slot,
                           const int32_t *n_leaf, int32_t *next_list, int32_t *next_count, int32_t *zero_count, int max_leaves,
-                          hipStream_t s);
+                          hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 double resnet_flops_per_board(const ResNetDev *);
 double resnet_exec_flops_per_board(const ResNetDev *, int game, int max_leaves);   // matrix-pipe FLOP executed per board (variant of that capacity)
 double resnet_exec_flops_total(const ResNetDev *, bool reset);   // summed on the device over every launch since the last reset
@@ -221,7 +222,7 @@ void resnet16_destroy(ResNet16Dev *);
 int resnet16_load(ResNet16Dev *, const float *blob, size_t n_floats, hipStream_t s);
 void resnet16_forward(ResNet16Dev *, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
                       int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, bool by_count = false,
-                      double *flop_acc = nullptr, double wg_flops = 0.0);
+                      double *flop_acc = nullptr, double wg_flops = 0.0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 double resnet16_wg_flops(const ResNet16Dev *, double flops_per_board);      // fp16 MFMA FLOP one 6-board workgroup executes
 
 }  // namespace azsp

@@ -400,32 +400,34 @@ bool resnet_has_fused(const ResNetDev *n, int game, int max_leaves, int tab_lds)
 
 static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
                          int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, const FusedArgs *fused,
-                         bool by_count = false);
+                         bool by_count = false, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 void resnet_forward(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
-                    int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, bool by_count) {
-    forward_impl(n, game, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s, nullptr, by_count);
+                    int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, bool by_count,
+                    hipEvent_t ev_start, hipEvent_t ev_stop) {
+    forward_impl(n, game, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s, nullptr, by_count,
+                 ev_start, ev_stop);
 }
 
 // One FUSED round of a slot group: evaluates the leaves listed in leaf_slot[0 .. *n_leaf) and carries those games on
 // (expansion, backup, next descent); their next leaves land in next_list / next_count, zero_count is cleared.
 void resnet_forward_fused(ResNetDev *n, int game, const View &view, const u64 *leaf0, int board_stride, const int32_t *leaf_slot,
                           const int32_t *n_leaf, int32_t *next_list, int32_t *next_count, int32_t *zero_count, int max_leaves,
-                          hipStream_t s) {
+                          hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
     FusedArgs f;
     f.v = view;
     f.next_list = next_list;
     f.next_count = next_count;
     f.zero_count = zero_count;
-    forward_impl(n, game, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, nullptr, 0, nullptr, 0, s, &f);
+    forward_impl(n, game, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, nullptr, 0, nullptr, 0, s, &f, false, ev_start, ev_stop);
 }
 
 static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
                          int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, const FusedArgs *fused,
-                         bool by_count) {
+                         bool by_count, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n->f16) {
         resnet16_forward(n->f16, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s, by_count,
-                         n->d_flop_acc, resnet16_wg_flops(n->f16, n->flops_per_board));
+                         n->d_flop_acc, resnet16_wg_flops(n->f16, n->flops_per_board), ev_start, ev_stop);
         return;
     }
     const Variant *v = pick_variant(n, game, max_leaves);
@@ -450,6 +452,8 @@ static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_str
     P.wg_flops = variant_wg_flops(n, v, nullptr);
     a.mine = leaf0; a.theirs = leaf0 + n->g_words; a.bstride = board_stride; a.leaf_slot = leaf_slot; a.n_leaf = n_leaf; a.max_leaves = max_leaves;
     a.out_p = out_p; a.out_v = out_v; a.p_stride = p_stride; a.v_stride = v_stride; a.s = s;
+    a.ev_start = ev_start;
+    a.ev_stop = ev_stop;
     if (fused) { fused_launcher(n, game, max_leaves)(a); return; }
     if (!by_count || n->forced_variant >= 0) { v->launch(a); return; }
     // by_count (evaluation cache): the list's length is known only on the device and varies from 1 to max_leaves.  Every
@@ -458,7 +462,8 @@ static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_str
     // (tuning knob AZSP_RESNET_GATES="a,b": upper ends of the first two ranges, multiples of 16; the variants return the same bits)
     static const int gate_env[2] = {[] { const char *x = getenv("AZSP_RESNET_GATES"); return x ? atoi(x) / 16 * 16 : -1; }(),
                                     [] { const char *x = getenv("AZSP_RESNET_GATES"); const char *c = x ? strchr(x, ',') : nullptr; return c ? atoi(c + 1) / 16 * 16 : -1; }()};
-    int prev = 0, k = 0;
+    struct Pick { const Variant *w; int lo, hi; } picks[8];
+    int prev = 0, k = 0, np = 0;
     for (const Variant &w : VARIANTS) {
         if (w.game != game || w.nt != n->g.NT) continue;
         if (prev >= max_leaves) break;
@@ -466,11 +471,17 @@ static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_str
         if (hi != INT_MAX && k < 2 && gate_env[k] >= 0) hi = gate_env[k];
         ++k;
         if (hi <= prev) continue;                        // an empty range: this variant is never the one
+        picks[np++] = {&w, prev, hi};
+        prev = hi;
+    }
+    for (int i = 0; i < np; ++i) {                       // the timing events span the whole group of launches
+        const Variant &w = *picks[i].w;
         P.perm = n->d_perm ? n->d_perm + w.perm_offset : nullptr;
         P.wg_flops = variant_wg_flops(n, &w, nullptr);
-        a.gate = (prev / 16) | ((hi == INT_MAX ? 0 : hi / 16) << 16);
+        a.gate = (picks[i].lo / 16) | ((picks[i].hi == INT_MAX ? 0 : picks[i].hi / 16) << 16);
+        a.ev_start = i == 0 ? ev_start : nullptr;
+        a.ev_stop = i == np - 1 ? ev_stop : nullptr;
         w.launch(a);
-        prev = hi;
     }
 }
 

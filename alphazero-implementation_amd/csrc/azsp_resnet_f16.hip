@@ -24,6 +24,8 @@
 #include <atomic>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "azsp_internal.h"
 #include "azsp_resnet_host.h"
 
@@ -726,7 +728,8 @@ int resnet16_load(ResNet16Dev *n, const float *blob, size_t n_floats, hipStream_
 
 template <int CT, int WR, int ABL = 0>
 static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, int bstride, const int32_t *leaf_slot, const int32_t *n_leaf,
-                     int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s) {
+                     int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s,
+                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     using G = Connect4;
     constexpr int WAVES = WR * CT, RS = 32 * CT + 8, TB = F16_ROWS / G::CELLS;
     constexpr size_t planes = (size_t)2 * (F16_ROWS + 1) * RS * 2;
@@ -747,7 +750,8 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, i
     const int grid = (cap + TB - 1) / TB;
     Net16Params Q = P;
     Q.perm = P.perm + (size_t)(WR == 1 ? 0 : WR == 2 ? 1 : WR == 4 ? 2 : 3) * F16_ROWS;      // row order of this wave grid
-    hipLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR, ABL>), dim3(grid), dim3(64 * WAVES), lds, s, Q, mine, theirs, bstride, leaf_slot, n_leaf, out_p, out_v, p_stride, v_stride);
+    hipExtLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR, ABL>), dim3(grid), dim3(64 * WAVES), lds, s, ev_start, ev_stop, 0, Q, mine, theirs,
+                          bstride, leaf_slot, n_leaf, out_p, out_v, p_stride, v_stride);
 }
 
 // Every workgroup of this kernel holds 6 boards (252 of 256 GEMM rows) in the tap-skipping row order and issues three fp16
@@ -760,7 +764,8 @@ double resnet16_wg_flops(const ResNet16Dev *n, double flops_per_board) {
 
 void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32_t *leaf_slot, const int32_t *n_leaf,
                       int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, bool by_count,
-                      double *flop_acc, double wg_flops) {
+                      double *flop_acc, double wg_flops, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    (void)by_count;
     const u64 *mine = leaf0, *theirs = leaf0 + Connect4::W;
     Net16Params P;
     unsigned char *d = n->d_blob;
@@ -779,7 +784,7 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
     P.gate = 0;
     // wave grid WR x CT over the 256-row x C tile (tuning knob AZSP_F16_WR; results do not depend on it)
     static const int wr_env = [] { const char *e = getenv("AZSP_F16_WR"); return e ? atoi(e) : 0; }();
-#define L16(CTV, WRV) launch16<CTV, WRV>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s)
+#define L16(CTV, WRV) launch16<CTV, WRV>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s, ev_start, ev_stop)
     switch (n->CT) {
         case 1:
             if (wr_env == 8 || (!wr_env && max_leaves <= 768)) L16(1, 8); else L16(1, 4);

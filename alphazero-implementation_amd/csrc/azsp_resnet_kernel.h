@@ -36,6 +36,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "azsp_internal.h"
 #include "azsp_resnet_host.h"
 #include "azsp_tree_dev.h"
@@ -1235,6 +1237,9 @@ struct FwdArgs {
     hipStream_t s;
     const FusedArgs *fused;                 // FUSED variants only, else nullptr
     int gate = 0;                           // (lo / 16) | (hi / 16) << 16: run only for list lengths in (lo, hi]; 0 = always
+    // AZSP_FLAG_TIMING: events that take the launch's own start / end timestamps from its dispatch packet
+    // (hipExtLaunchKernelGGL) -- no extra packets between dependent kernels, unlike hipEventRecord around the launch
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 
 // tracing state lives in azsp_resnet.hip (one copy for all kernel translation units)
@@ -1291,11 +1296,12 @@ static void launch_forward(const FwdArgs &a) {
         }
     }
     if constexpr (FUSED) {
-        hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW, false, true>), dim3(grid), dim3(64 * RW * CW), lds, a.s, a.P, a.mine,
-                           a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, a.p_stride, a.v_stride, *a.fused);
+        hipExtLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW, false, true>), dim3(grid), dim3(64 * RW * CW), lds, a.s, a.ev_start,
+                              a.ev_stop, 0, a.P, a.mine, a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, a.p_stride, a.v_stride,
+                              *a.fused);
     } else {
-        hipLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW>), dim3(grid), dim3(64 * RW * CW), lds, a.s, a.P, a.mine, a.theirs,
-                           a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, a.p_stride, a.v_stride, a.gate);
+        hipExtLaunchKernelGGL((k_resnet_forward<G, NT, MT, PF, CW, RW>), dim3(grid), dim3(64 * RW * CW), lds, a.s, a.ev_start, a.ev_stop, 0,
+                              a.P, a.mine, a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.out_p, a.out_v, a.p_stride, a.v_stride, a.gate);
     }
 }
 

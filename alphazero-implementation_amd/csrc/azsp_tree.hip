@@ -24,6 +24,8 @@
 // R = 2 is rule set 0 with the float64 value sums numpy 1.x would produce (see include/azsp.h).
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "azsp_internal.h"
 #include "azsp_tree_dev.h"
 
@@ -634,12 +636,13 @@ void launch_compact(const View &v, hipStream_t s) { hipLaunchKernelGGL(k_compact
 void launch_eval_hash(int game, const View &v, uint64_t salt, hipStream_t s) {
     GAME_SWITCH(game, hipLaunchKernelGGL(k_eval_hash<G>, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v, salt));
 }
-void launch_expand(int game, const View &v, hipStream_t s) {
-    RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expand<G, R>), dim3(games_grid<G>(v.n_act)), dim3(64), 0, s, v));
+// (ea / eb: optional timing events that take the launch's own start / end timestamps from its dispatch packet)
+void launch_expand(int game, const View &v, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+    RULES_SWITCH(game, v.rules, hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_expand<G, R>), dim3(games_grid<G>(v.n_act)), dim3(64), 0, s, ea, eb, 0, v));
 }
-void launch_expand_select(int game, const View &v, hipStream_t s) {
-    RULES_SWITCH(game, v.rules, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expand_select<G, R>), dim3(games_grid<G>(v.n_act)), dim3(64),
-                                                    (tree_lds_bytes<G, R>(v)), s, v));
+void launch_expand_select(int game, const View &v, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+    RULES_SWITCH(game, v.rules, hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_expand_select<G, R>), dim3(games_grid<G>(v.n_act)), dim3(64),
+                                                       (uint32_t)(tree_lds_bytes<G, R>(v)), s, ea, eb, 0, v));
 }
 void launch_leaf_cells(int game, const View &v, int8_t *dst, hipStream_t s) {
     GAME_SWITCH(game, hipLaunchKernelGGL(k_leaf_cells<G>, dim3((v.n_act + 255) / 256), dim3(256), 0, s, v, dst));

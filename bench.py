@@ -217,6 +217,9 @@ def main() -> None:
     ap.add_argument("--single", action="store_true", help="measure only --precision")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the in-kernel clock measurement after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timing-sample", type=int, default=4,
+                    help="evaluation-cache runs: HIP events around the kernels of 8 consecutive simulation rounds out of every 8 * N "
+                         "(1 = every launch, as the runs without the cache always do)")
     ap.add_argument("--no-eval-cache", action="store_true", help="skip the evaluation-cache measurements")
     ap.add_argument("--eval-cache-headline", action="store_true", help="diagnostics: make the evaluation-cache run the top-level line")
     ap.add_argument("--game", choices=["connect4", "gomoku9"], default="connect4",
@@ -286,7 +289,10 @@ def main() -> None:
             gen = None
         else:
             gen = azsp.EpisodeGenerator(game=game_cls(), config=cfg, device=local_rank, timing=True, n_groups=args.groups,
-                                        f16_split=precision == "f16x2", eval_cache=eval_cache)
+                                        f16_split=precision == "f16x2", eval_cache=eval_cache,
+                                        # sampled event windows only where launches do not overlap (one slot group): with
+                                        # three groups the union of a window's intervals misses its untimed neighbours
+                                        timing_sample=args.timing_sample if eval_cache and args.groups <= 1 else 1)
 
         def step(seed: int):
             if rehearse:
@@ -328,11 +334,16 @@ def main() -> None:
                     "episodes": episodes, "samples": samples, "ranks": ranks, "roofline": None, "tree": None}
         eng.close()
         launches = max(int(st["infer_launches"]), 1)
-        avg_ms = st["infer_ms"] / launches
+        # The events sit on the launches of 8 consecutive simulation rounds out of every 8 * --timing-sample (timestamps on
+        # a dispatch cost a few microseconds each -- 5-9 % of the step where a round is launch latency); durations and
+        # overlap are measured on those launches and the busy time scaled to all of them.
+        timed = max(int(st["infer_launches_timed"]), 1)
+        avg_ms = st["infer_ms"] / timed
         # Launches of different slot groups run concurrently on separate streams, so the rate is taken over the
         # union of the launch intervals: flops per launch / (average launch duration / overlap factor).
-        union_ms = st["infer_union_ms"] if st["infer_union_ms"] > 0 else st["infer_ms"]
-        overlap = st["infer_ms"] / union_ms if union_ms > 0 else 1.0
+        union_timed = st["infer_union_ms"] if st["infer_union_ms"] > 0 else st["infer_ms"]
+        overlap = st["infer_ms"] / union_timed if union_timed > 0 else 1.0
+        union_ms = union_timed * launches / timed
         peak = PEAK_TFLOPS[precision]
         boards = st["infer_boards"]                  # positions the kernel evaluated (== evals unless the evaluation cache is on)
         # EXECUTED matrix-pipe FLOP, summed on the device: every inference launch adds (workgroups that had boards) x (what
@@ -358,7 +369,7 @@ def main() -> None:
                          "executed_flops_per_board": efpb, "flops_per_board": fpb,
                          "algorithmic_achieved": algorithmic, "algorithmic_frac": algorithmic / peak,
                          "frac_over_wall": tf(exec_flops, dt * 1e3) / peak,
-                         "boards_per_launch": boards / launches, "avg_launch_ms": avg_ms, "launches": launches,
+                         "boards_per_launch": boards / launches, "avg_launch_ms": avg_ms, "launches": launches, "launches_timed": timed,
                          "concurrent_launches": overlap, "busy_ms": union_ms,
                          # the same without the overlap factor: one launch's executed flops / its own duration (the
                          # launches of the slot groups share the machine: a per-launch share, not the machine's rate)

@@ -114,6 +114,10 @@ typedef struct azsp_config {
     int32_t  search_rules;   /* AZSP_RULES_*                                                           */
     int32_t  eval_cache_entries; /* AZSP_FLAG_EVAL_CACHE: table entries (64 B each, rounded up to a power of two,
                                     at most 2^26); 0 = automatic (64 * n_slots * (n_sims + 1))              */
+    int32_t  timing_sample;  /* AZSP_FLAG_TIMING: n > 1 = time the kernels of 8 consecutive simulation rounds out of
+                                every 8 n only (timestamps on a dispatch cost a few microseconds each, which
+                                matters where a round is launch latency); 0 / 1 = every launch            */
+    int32_t  reserved;       /* 0                                                                      */
 } azsp_config;
 
 /* Host evaluator: boards int8[n][cells] (canonical) -> p float32[n][n_actions], v float32[n].
@@ -154,6 +158,7 @@ typedef struct azsp_stats {
                                           slot of a full workgroup: padding rows included, statically skipped
                                           off-board taps excluded, x 3 for the split-fp16 kernel (hi*hi, hi*lo, lo*hi) */
     uint64_t eval_cache_entries;       /* table size in use (0 = cache off)                              */
+    uint64_t infer_launches_timed;     /* how many of infer_launches carried timing events (infer_ms / infer_union_ms cover these) */
     double   infer_exec_flops;         /* matrix-pipe FLOP executed by all inference launches, summed ON THE DEVICE: every
                                           launch adds (workgroups that had boards) x (FLOP one workgroup of that variant
                                           executes) -- exact per workgroup, whichever variant ran                      */

@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cache", action="store_true")
 ap.add_argument("--f16", action="store_true")
 ap.add_argument("--timing", action="store_true")
+ap.add_argument("--timing-sample", type=int, default=0)
 ap.add_argument("--slots", type=int, default=4096)
 ap.add_argument("--sims", type=int, default=100)
 ap.add_argument("--groups", type=int, default=0)
@@ -21,7 +22,7 @@ a = ap.parse_args()
 torch.manual_seed(0)
 net = azsp.ResNet((6, 7), 7, a.blocks, a.channels).eval()
 gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, a.sims, a.slots, 1, 1), timing=a.timing,
-                            n_groups=a.groups, f16_split=a.f16, eval_cache=a.cache)
+                            n_groups=a.groups, f16_split=a.f16, eval_cache=a.cache, timing_sample=a.timing_sample)
 np.random.seed(1000)
 n = sum(1 for _ in gen.generate_episodes(net))
 torch.cuda.synchronize()
