@@ -286,7 +286,9 @@ static int search_enqueue(azsp_engine *e, int n_act) {
     // Only up to 32 games, where a round is launch latency (one game 106.6 -> 101.0 us per round); for large batches the
     // same idea measured SLOWER (2101 against 2209 episodes/s: the tree step is a chain of dependent loads during which
     // the workgroup's other waves idle) and its kernels were retired after round 2.
-    bool fused_rounds = e->fused_rounds_small && e->evaluator == AZSP_EVAL_RESNET && e->net && e->net_loaded &&
+    // (Not with the evaluation cache: a round whose leaves are all known then costs a tree launch and an empty inference
+    // launch, ~20 us instead of ~100 -- one game, 100 simulations: 24 % of the rounds.)
+    bool fused_rounds = e->fused_rounds_small && e->evaluator == AZSP_EVAL_RESNET && e->net && e->net_loaded && e->d_ent == nullptr &&
                         e->cfg.search_rules == AZSP_RULES_SIMPLE && !e->v.reuse && e->v.root_noise == nullptr;
     View gv[MAX_GROUPS];
     for (int k = 0; k < G; ++k) {

@@ -113,6 +113,11 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
     n->o_conv_w = reserve(n->conv_w_stride * 2 * blocks);
     n->o_conv_b = reserve(n->conv_b_stride * 2 * blocks);
     if ((game == 0 && (g.NT == 2 || g.NT == 4)) || (game == 2 && g.NT >= 3)) { n->has_w4 = true; n->o_conv_w4 = reserve(n->conv_w_stride * 2 * blocks); }
+    if (game == 0 && (g.NT == 2 || g.NT == 4)) {      // the one-board kernels on 16-row tiles: slot-ordered weights and biases
+        n->has_w16 = true;
+        n->o_conv_w16 = reserve(n->conv_w_stride * 2 * blocks);
+        n->o_conv_b16 = reserve(n->conv_b_stride * 2 * blocks);
+    }
     n->o_pol_w = reserve((size_t)g.S * 64);
     n->o_pol_b = reserve(32);
     n->o_val_w = reserve((size_t)9 * g.Cp * 4);
@@ -204,6 +209,27 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
                                 src[(((size_t)tap * g.S + sidx) * 64 + lane) * g.NT + nt];
         }
         for (int o = 0; o < g.C; ++o) host[n->o_conv_b + (size_t)l * n->conv_b_stride + o] = b[o];
+        if (n->has_w16) {
+            // conv_tile16c: [tap][16-channel input group][16-channel output tile][lane][4]; lane = (A row m = output SLOT of the
+            // tile) + 16 * quarter; element j = input channel 16 * group + t16_chan(quarter, j); slot m = channel t16_chan(m >> 2, m & 3)
+            float *dst = host.data() + n->o_conv_w16 + (size_t)l * n->conv_w_stride;
+            const int G16 = g.Cp / 16;
+            for (int tap = 0; tap < 9; ++tap)
+                for (int sg = 0; sg < G16; ++sg)
+                    for (int ct = 0; ct < G16; ++ct)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j) {
+                                const int m = lane & 15, q = lane >> 4;
+                                const int o = ct * 16 + t16_chan(m >> 2, m & 3), i = 16 * sg + t16_chan(q, j);
+                                dst[((((size_t)tap * G16 + sg) * G16 + ct) * 64 + lane) * 4 + j] =
+                                    (o < g.C && i < g.C) ? w[((size_t)o * g.C + i) * 9 + tap] : 0.0f;
+                            }
+            float *bd = host.data() + n->o_conv_b16 + (size_t)l * n->conv_b_stride;
+            for (int sl = 0; sl < g.Cp; ++sl) {
+                const int o = (sl & ~15) + t16_chan((sl & 15) >> 2, sl & 3);
+                bd[sl] = o < g.C ? b[o] : 0.0f;
+            }
+        }
     }
     {
         ConvBN c = take_conv_bn(p, POL_CH, g.C, 1);
@@ -315,10 +341,10 @@ struct Variant {
 };
 static const Variant VARIANTS[] = {
     {"c4_32_small", 0, 1, 768, fwd_c4_32_small, 0, 1, 1, 1, 4},   {"c4_32_big", 0, 1, INT_MAX, fwd_c4_32_big, 0, 2, 0, 1, 4},
-    {"c4_64_one", 0, 2, 320, fwd_c4_64_one, 0, 1, 0, 2, 2},       {"c4_64_mid", 0, 2, 768, fwd_c4_64_mid, 0, 2, 0, 2, 2},
+    {"c4_64_one", 0, 2, 320, fwd_c4_64_one, 0, 1, 2, 2, 2},       {"c4_64_mid", 0, 2, 768, fwd_c4_64_mid, 0, 2, 0, 2, 2},
     {"c4_64_big", 0, 2, INT_MAX, fwd_c4_64_big, 256, 4, 0, 2, 2},
     {"c4_96", 0, 3, INT_MAX, fwd_c4_96, 0, 1, 1, 1, 4},
-    {"c4_128_one", 0, 4, 512, fwd_c4_128_one, 0, 1, 0, 4, 2},     {"c4_128_mid", 0, 4, 768, fwd_c4_128_mid, 0, 2, 0, 4, 2},
+    {"c4_128_one", 0, 4, 512, fwd_c4_128_one, 0, 1, 2, 4, 2},     {"c4_128_mid", 0, 4, 768, fwd_c4_128_mid, 0, 2, 0, 4, 2},
     {"c4_128_big", 0, 4, INT_MAX, fwd_c4_128_big, 256, 4, 0, 4, 2},
     {"c4_192", 0, 6, INT_MAX, fwd_c4_192, 0, 2, 1, 3, 2},         {"c4_256", 0, 8, INT_MAX, fwd_c4_256, 0, 2, 1, 4, 2},
     {"g9_32", 2, 1, INT_MAX, fwd_g9_32, 0, 2, 0, 1, 4},           {"g9_64", 2, 2, INT_MAX, fwd_g9_64, 0, 2, 0, 1, 4},
@@ -348,7 +374,8 @@ static double variant_wg_flops(const ResNetDev *n, const Variant *v, int *boards
     const int wg_rows = v->rw * 32 * v->mt, tb = wg_rows / g.cells;
     const bool sk = v->game == 0 && v->pf == 0 && ((v->mt == 2 && v->rw == 4) || (v->mt == 4 && v->rw == 2 && v->cw == v->nt));
     const bool tile16 = v->game == 2 && v->pf == 0 && v->cw == v->nt && v->rw == 1 && v->mt == 3 && v->nt >= 3;
-    const double rows = tile16 ? cells * tb : (double)wg_rows;         // GEMM rows the workgroup computes
+    const bool tile16c = v->game == 0 && v->pf == 2;                    // one Connect-4 board on three 16-row tiles
+    const double rows = tile16 ? cells * tb : (tile16c ? 48.0 : (double)wg_rows);      // GEMM rows the workgroup computes
     if (boards_per_wg) *boards_per_wg = tb;
     return tower * (rows / cells) * (sk ? 5.0 / 6.0 : 1.0) * pad_ch + rest * tb;
 }
@@ -448,6 +475,8 @@ static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_str
     P.dbg = nullptr;
     P.perm = n->d_perm ? n->d_perm + v->perm_offset : nullptr;
     P.conv_w4 = n->has_w4 ? d + n->o_conv_w4 : nullptr;
+    P.conv_w16 = n->has_w16 ? d + n->o_conv_w16 : nullptr;
+    P.conv_b16 = n->has_w16 ? d + n->o_conv_b16 : nullptr;
     P.flop_acc = n->d_flop_acc;
     P.wg_flops = variant_wg_flops(n, v, nullptr);
     a.mine = leaf0; a.theirs = leaf0 + n->g_words; a.bstride = board_stride; a.leaf_slot = leaf_slot; a.n_leaf = n_leaf; a.max_leaves = max_leaves;

@@ -67,6 +67,8 @@ struct ResNetDev {
     int32_t *d_perm = nullptr;    // [2][256] row orders of the tap-skipping Connect-4 kernels: 4x1 and 2x2 wave grids
     size_t o_conv_w4 = 0;         // quad-k-step copy of the conv weights (64-channel Connect-4 nets)
     bool has_w4 = false;
+    size_t o_conv_w16 = 0, o_conv_b16 = 0;   // slot-ordered copies for the Connect-4 one-board kernels on 16-row tiles
+    bool has_w16 = false;
     int g_words = 1;              // 64-bit words per side of a position (game trait W)
     int forced_variant = -1;      // index into the variant table if AZSP_RESNET_VARIANT named one at creation, else -1
     double *d_flop_acc = nullptr; // executed matrix-pipe FLOP of every launch since the last reset (both kernels add to it)
@@ -87,6 +89,9 @@ struct NetParams {
     const int32_t *perm;          // [256] GEMM row -> board-cell row of the tap-skipping row order (see build_row_order)
     const float *conv_w4;         // conv weights as [tap][s / 4][column tile][lane][4 k-steps] (one 16-byte load per lane
                                   // feeds four k-steps of a wave that owns ONE column tile), else nullptr
+    const float *conv_w16;        // Connect-4 one-board kernels (16-row tiles): conv weights as [tap][16-channel input group][16-channel
+                                  // output tile][lane][4] in SLOT order (t16_chan), conv_b16: the biases in slot order; else nullptr
+    const float *conv_b16;
     double *flop_acc;             // device accumulator of EXECUTED matrix-pipe FLOP (one atomic per launch), or nullptr
     double wg_flops;              // what one workgroup of this variant executes (resnet_exec_flops_per_board x boards per workgroup)
 };
@@ -525,6 +530,59 @@ __device__ __forceinline__ void conv_tile16(f32x4m (&acc)[5][2], float (&vacc)[2
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 16-row tiles for ONE Connect-4 board per workgroup (small batches: a round there is this workgroup's latency)
+// ------------------------------------------------------------------------------------------------
+// 42 cells in 32-row tiles are 64 GEMM rows; in 16-row tiles 48: a quarter less matrix-pipe time per layer on the one CU
+// the board runs on.  The variants of a network must return the SAME BITS (the engine picks them by batch size), and an
+// fp32 MFMA of either shape is a chain of fused multiply-adds in k order (tools/probe/mfma_order.hip: 0 of 51 200 results
+// differ), so the 16x16x4 form only has to meet the channel order of the 32-row kernels: per 8-channel block c, c+4, c+1,
+// c+5, c+2, c+6, c+3, c+7 (koff).  MFMA j of a 16-channel group then takes the channels  j = 0: 0 4 1 5,  1: 2 6 3 7,
+// 2: 8 12 9 13,  3: 10 14 11 15  -- lane quarter q supplies t16_chan(q, j).  Inside this kernel's tower the activations sit
+// in LDS in SLOT order (slot 4 q + j of a 16-group holds channel t16_chan(q, j)), so that a quarter's four values are one
+// 16-byte read; the weights' A rows are permuted the same way, which makes a lane's four results four consecutive slots
+// (one 16-byte store).  One pass converts the stem's output to slot order, one converts the tower's output back.
+__host__ __device__ constexpr int t16_chan(int q, int j) { return 4 * (q & 1) + (q >> 1) + 2 * (j & 1) + 8 * (j >> 1); }
+
+// A wave owns ONE 16-channel output tile x NRT row tiles.  Same rolled software pipeline as conv_tile16.
+template <class G, int NRT, int SPT, int NT, int STRIDE>
+__device__ __forceinline__ void conv_tile16c(f32x4m (&acc)[NRT], const float *act, const int (&ridx)[NRT], const uint32_t (&vmask)[NRT],
+                                             int zero_idx, const float *wq, float4 (&wb)[Tile16Geo<SPT>::QC]) {
+    constexpr int QC = Tile16Geo<SPT>::QC, CPT = SPT / QC, NCHUNK = 9 * CPT, BODY = NRT * QC;
+    constexpr size_t QSTR = (size_t)2 * NT * 64 * 4;                  // floats between consecutive 16-channel input groups
+    static_assert(SPT % QC == 0 && BODY % 4 == 0 && QC >= 2, "chunking");
+    float4 xa[4];
+    int base[NRT];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) base[t] = tower_aindex<G, STRIDE>(ridx[t], vmask[t], 0, zero_idx);
+    xa[0] = *reinterpret_cast<const float4 *>(act + base[0]);
+    xa[1] = *reinterpret_cast<const float4 *>(act + base[0] + 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int cn = c + 1 < NCHUNK ? c + 1 : c;
+        const int tapn = cn / CPT, q0n = (cn % CPT) * QC;
+        const int nbase0 = tower_aindex<G, STRIDE>(ridx[0], vmask[0], tapn, zero_idx) + 16 * q0n;
+        const int q0 = (c % CPT) * QC;
+        const float *wnext = wq + (size_t)(c * QC + QC) * QSTR;       // group 0 of the next chunk
+#pragma unroll
+        for (int i = 0; i < BODY; ++i) {
+            const int t = i / QC, q = i % QC;
+            const int j = i + 2;                                      // the step whose activations are requested now
+            if (j < BODY) xa[j % 4] = *reinterpret_cast<const float4 *>(act + base[j / QC] + 16 * (q0 + j % QC));
+            else xa[j % 4] = *reinterpret_cast<const float4 *>(act + nbase0 + 16 * (j - BODY));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[t] = conv_mma16(f4c(xa[i % 4], k), f4c(wb[q], k), acc[t]);
+            if (t == NRT - 1) wb[q] = *reinterpret_cast<const float4 *>(wnext + (size_t)q * QSTR);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (cn != c && cn % CPT == 0) {                               // the next chunk opens a new tap
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) base[t] = tower_aindex<G, STRIDE>(ridx[t], vmask[t], tapn, zero_idx);
+        }
+    }
+}
+
 // (C/D layout of v_mfma_f32_32x32x2_f32: register v of lane l holds row (v & 3) + 8 * (v >> 2) + 4 * (l >> 5), column
 // l & 31 -- with the weights on the A side the row is the output channel and the column the board cell: conv_mma above)
 
@@ -549,7 +607,12 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     // every other wave grid with one column tile per wave: the rolled form of the same software pipeline (conv_rolled)
     // one 9x9 board per workgroup from 96 channels on: the tower on five 16-row tiles + the corner cell (conv_tile16)
     constexpr bool TILE16 = std::is_same<G, Gomoku9>::value && PF == 0 && CW == NT && RW == 1 && MT == 3 && NT >= 3;
-    constexpr bool ROLLED = !STATIC_TOWER && !TILE16 && PF == 0 && CW == NT && NT >= 2;
+    // one Connect-4 board per workgroup on three 16-row tiles (conv_tile16c): PF == 2 marks these instantiations; every
+    // wave owns one 16-channel output tile
+    constexpr bool TILE16C = std::is_same<G, Connect4>::value && PF == 2;
+    static_assert(!TILE16C || (MT == 1 && WG_ROWS / CELLS == 1 && RW * CW * 16 == 32 * NT), "one board, one 16-channel tile per wave");
+    constexpr int PFE = PF == 2 ? 0 : PF;          // (the prefetch form of the other convolutions)
+    constexpr bool ROLLED = !STATIC_TOWER && !TILE16 && !TILE16C && PF == 0 && CW == NT && NT >= 2;
     constexpr int WBN = ROLLED ? RolledGeo<S / 4>::QC : 8;
     constexpr int SPT16 = CP / 16, QC16 = Tile16Geo<SPT16>::QC;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -736,6 +799,94 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
 #pragma unroll
         for (int j = 0; j < WBN; ++j) wb[j] = *reinterpret_cast<const float4 *>(wq0 + (size_t)j * NT * 64 * 4);
     }
+    if constexpr (TILE16C) {
+        // ---- the whole tower on three 16-row tiles (cells 0..47: 42 real), activations in slot order ----
+        constexpr int CP16 = CP / 4, ITEMS = 48 * CP16, PER = (ITEMS + NTHREADS - 1) / NTHREADS;
+        const int nl = 2 * P.blocks;
+        if (nl > 0) {
+            float4 mv[PER];
+#pragma unroll
+            for (int it = 0; it < PER; ++it) {          // natural -> slot order: slots 4 q .. 4 q + 3 of a 16-group <- channels t16_chan(q, 0..3)
+                const int item = tid + it * NTHREADS, row = item / CP16, g4 = item % CP16, q = g4 & 3;
+                const float *src = act + row * STRIDE + 16 * (g4 >> 2);
+                if (item < ITEMS) mv[it] = make_float4(src[t16_chan(q, 0)], src[t16_chan(q, 1)], src[t16_chan(q, 2)], src[t16_chan(q, 3)]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < PER; ++it) {
+                const int item = tid + it * NTHREADS, row = item / CP16, g4 = item % CP16;
+                if (item < ITEMS) *reinterpret_cast<float4 *>(act + row * STRIDE + 4 * g4) = mv[it];
+            }
+            __syncthreads();
+            const int c16 = 16 * (tid >> 6);            // this wave's 16-channel output tile (slots c16 .. c16 + 15)
+            int rix[3];
+            uint32_t vmk[3];
+            f32x4m a16[3], xr16[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int pos = 16 * t + l15, y = pos / COLS, x = pos % COLS;
+                uint32_t m = 0;
+                if (pos < CELLS && board0 < n_leaf)
+                    for (int tp = 0; tp < 9; ++tp) {
+                        const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                        if (yy >= 0 && yy < ROWS && xx >= 0 && xx < COLS) m |= 1u << tp;
+                    }
+                vmk[t] = m;
+                rix[t] = pos * STRIDE + 4 * kq;
+            }
+            {   // block input + the bias of the block's second convolution, from what the stem stored
+                const float4 bq = *reinterpret_cast<const float4 *>(P.conv_b16 + (size_t)P.conv_b_stride + c16 + 4 * kq);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const float4 x = *reinterpret_cast<const float4 *>(act + rix[t] + c16);
+                    xr16[t] = (f32x4m){x.x + bq.x, x.y + bq.y, x.z + bq.z, x.w + bq.w};
+                }
+            }
+            float4 wbc[QC16];
+            const float *wq0 = P.conv_w16 + ((size_t)(tid >> 6) * 64 + lane) * 4;
+#pragma unroll
+            for (int j = 0; j < QC16; ++j) wbc[j] = *reinterpret_cast<const float4 *>(wq0 + (size_t)j * 2 * NT * 64 * 4);
+            for (int layer = 0; layer < nl; ++layer) {
+                const bool second = layer & 1;
+                const float *blc = P.conv_b16 + (size_t)layer * P.conv_b_stride + c16;
+                const bool fold = second && layer + 2 < nl;        // a next block exists: keep its input + bias
+                if (second) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) a16[t] = xr16[t];
+                } else {
+                    const float4 bq = *reinterpret_cast<const float4 *>(blc + 4 * kq);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) a16[t] = (f32x4m){bq.x, bq.y, bq.z, bq.w};
+                }
+                conv_tile16c<G, 3, SPT16, NT, STRIDE>(a16, act, rix, vmk, ZERO_IDX + 4 * kq, wq0 + (size_t)layer * P.conv_w_stride, wbc);
+                if (layer < 16) STAMP(3 + 3 * layer);
+                float4 b2q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (fold) b2q = *reinterpret_cast<const float4 *>(blc + 2 * (size_t)P.conv_b_stride + 4 * kq);
+                __syncthreads();                           // every wave is done reading the layer input
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const float4 o = make_float4(relu(a16[t][0]), relu(a16[t][1]), relu(a16[t][2]), relu(a16[t][3]));
+                    *reinterpret_cast<float4 *>(act + rix[t] + c16) = o;
+                    if (fold) xr16[t] = (f32x4m){o.x + b2q.x, o.y + b2q.y, o.z + b2q.z, o.w + b2q.w};
+                }
+                __syncthreads();
+                if (layer < 16) STAMP(5 + 3 * layer);
+            }
+#pragma unroll
+            for (int it = 0; it < PER; ++it) {          // slot -> natural order for the heads
+                const int item = tid + it * NTHREADS, row = item / CP16, g4 = item % CP16;
+                if (item < ITEMS) mv[it] = *reinterpret_cast<const float4 *>(act + row * STRIDE + 4 * g4);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < PER; ++it) {
+                const int item = tid + it * NTHREADS, row = item / CP16, g4 = item % CP16, q = g4 & 3;
+                float *dst = act + row * STRIDE + 16 * (g4 >> 2);
+                if (item < ITEMS) { dst[t16_chan(q, 0)] = mv[it].x; dst[t16_chan(q, 1)] = mv[it].y; dst[t16_chan(q, 2)] = mv[it].z; dst[t16_chan(q, 3)] = mv[it].w; }
+            }
+            __syncthreads();
+        }
+    } else
     for (int layer = 0; layer < 2 * P.blocks; ++layer) {
         const bool second = layer & 1;
         const float *wl = P.conv_w + (size_t)layer * P.conv_w_stride;
@@ -819,7 +970,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
             const float *wq = P.conv_w4 + (size_t)layer * P.conv_w_stride + ((size_t)wc * 64 + lane) * 4;
             conv_rolled<G, MT, S / 4, NT, STRIDE>(acc, act, ridx, vmask, ZERO_IDX + 4 * half, wq, wb);
         } else {
-            conv_mfma<G, MT, NTW, 9, S, PF, NT, SK>(acc, wl + wc * NTW, act, ridx, vmask, STRIDE, ZERO_IDX + 4 * half, lane, need);
+            conv_mfma<G, MT, NTW, 9, S, PFE, NT, SK>(acc, wl + wc * NTW, act, ridx, vmask, STRIDE, ZERO_IDX + 4 * half, lane, need);
         }
         f32x16 b2[NTW];
         if constexpr (AHEAD) {
@@ -875,7 +1026,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
         }
     }
     if (pol_here)
-        conv_mfma<G, PMT, 1, 1, S, PF, 1, false>(accp, P.pol_w, act, pridx, pvmask, STRIDE, ZERO_IDX + 4 * half, lane, pneed);
+        conv_mfma<G, PMT, 1, 1, S, PFE, 1, false>(accp, P.pol_w, act, pridx, pvmask, STRIDE, ZERO_IDX + 4 * half, lane, pneed);
     STAMP(51);
     // The value conv has 3 output channels.  As a 32-wide MFMA tile it would cost +5.8 % MFMA time for 0.6 % of the
     // FLOPs; on the vector ALU it took 16 us of a 370 us workgroup (scalar weight loads and LDS reads sharing one
