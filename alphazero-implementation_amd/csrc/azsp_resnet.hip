@@ -329,7 +329,10 @@ void resnet_trace_report(const unsigned long long *h, int grid, bool print) {
 // Every variant returns the same bits for a position (tested: test_resnet_every_batch_regime_returns_the_same_bits);
 // the choice is by game, column tiles (NT = padded channels / 32) and the launch's board capacity -- measured
 // crossovers, DESIGN.md section 7: up to about one workgroup per CU a launch lasts as long as ONE workgroup, so small
-// batches take one board per workgroup, mid-size ones three, large ones six (tap skipping).
+// batches take one board per workgroup, mid-size ones three, large ones six (tap skipping).  Stand-alone launches, round 3
+// (one-board kernels on 16-row tiles), 64 channels: one 82 us up to 256 boards, 134-139 us up to 512, 195 us at 768;
+// mid 165-173 us up to 768; big 243-253 us up to 1536.  128 channels x 8 blocks: one 0.48 / 0.94 / 1.39 ms at 256 / 512 /
+// 768, mid 1.14-1.18 ms up to 768, big 1.77-1.80 ms up to 1536.
 // AZSP_RESNET_VARIANT=<name> (read once, when the network is created) forces a variant of matching game and width.
 struct Variant {
     const char *name;
@@ -341,7 +344,7 @@ struct Variant {
 };
 static const Variant VARIANTS[] = {
     {"c4_32_small", 0, 1, 768, fwd_c4_32_small, 0, 1, 1, 1, 4},   {"c4_32_big", 0, 1, INT_MAX, fwd_c4_32_big, 0, 2, 0, 1, 4},
-    {"c4_64_one", 0, 2, 320, fwd_c4_64_one, 0, 1, 2, 2, 2},       {"c4_64_mid", 0, 2, 768, fwd_c4_64_mid, 0, 2, 0, 2, 2},
+    {"c4_64_one", 0, 2, 512, fwd_c4_64_one, 0, 1, 2, 2, 2},       {"c4_64_mid", 0, 2, 768, fwd_c4_64_mid, 0, 2, 0, 2, 2},
     {"c4_64_big", 0, 2, INT_MAX, fwd_c4_64_big, 256, 4, 0, 2, 2},
     {"c4_96", 0, 3, INT_MAX, fwd_c4_96, 0, 1, 1, 1, 4},
     {"c4_128_one", 0, 4, 512, fwd_c4_128_one, 0, 1, 2, 4, 2},     {"c4_128_mid", 0, 4, 768, fwd_c4_128_mid, 0, 2, 0, 4, 2},
