@@ -818,6 +818,32 @@ def test_distributed_exact_mode_two_ranks_gloo_rehearsal(azsp):
         assert np.array_equal(np.array(pols), ref["policies"][lo:hi]) and vals == ref["values"][lo:hi].tolist()
 
 
+def test_bench_gpus2_launches_its_own_two_ranks_on_this_box(azsp):
+    """`python bench.py --gpus 2` with no launcher: bench.py starts its own two rank processes (one torch.distributed.run
+    child) and rank 0 prints ONE line with n_gpus 2 whose counts are both ranks'.  Here the two ranks share this box's one
+    GPU and exchange over gloo (AZSP_BENCH_BACKEND=gloo; with nccl the same command refuses: fewer GPUs than ranks) --
+    real engines, the real all-gather of exported records, the real rank combination."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--slots", "256", "--sims", "20", "--steps", "2", "--warmup", "1",
+            "--single", "--no-clock-probe", "--no-eval-cache"]
+    r = subprocess.run(args, env=dict(env, AZSP_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["episodes"] == 2 * 2 * 256 and len(out["ranks"]["ms_per_step"]) == 2
+    assert out["config"]["launched_by"].startswith("bench.py") and out["value"] > 0 and 0 < out["roofline"]["frac"] <= 1.0
+    import torch
+    if torch.cuda.device_count() < 2:                          # RCCL needs one GPU per rank: refused, no line, non-zero exit
+        r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and "{" not in r.stdout
+
+
 def test_reference_mcts_tests_intent_on_the_engine(azsp):
     """The reference's own (stale) MCTSTests, restated: Connect2 + fixed-prior mock evaluator through the
     MCTS facade (host-callback evaluator); visit counts equal the oracle's and satisfy the asserted orderings."""
