@@ -165,7 +165,8 @@ __device__ __forceinline__ void conv16s(f32x16 (&acc)[NTILE], const h8 *__restri
             l[sl] = wp[64];
         }
     };
-    constexpr bool DB = SL <= 4;            // double-buffer only while the registers last (<= 64 channels)
+    constexpr bool DB = SL <= 4;            // double-buffer only while the registers last (<= 64 channels; with more slabs the second
+                                            // buffer spills even in the one-board form: 9 x 128 launch 0.256 -> 0.367 ms)
     if constexpr (DB) load_b(0, nh, nl);
     for (int tap = 0; tap < TAPS; ++tap) {
         const int t9 = (TAPS == 9) ? tap : 4;
@@ -287,13 +288,19 @@ __device__ __forceinline__ void tower16_layer(f32x16 (&acc)[4], const unsigned c
     tower16_step<G, GROUP, SL, CT, ROW_BYTES, PLANE_BYTES, 0>(acc, lds, abyte, vmask, zero_byte, w, wh, wl, xh, xl, rbase);
 }
 
-template <class G, int CT, int WR, int ABL = 0>
+// NR = GEMM rows of a workgroup: 256 (six boards, tap-skipping row order; large batches), 128 (three boards) or 64 (ONE
+// board: small batches, where a simulation round is this workgroup's latency).  The smaller forms keep the boards' cells in
+// board order (identity row order); the sums of every output are taken in the same order in all of them (taps ascending,
+// 16-deep slabs ascending, hi*hi + hi*lo + lo*hi), so the variants return the same bits.
+template <class G, int CT, int WR, int ABL = 0, int NR = 256>
 __global__ __launch_bounds__(64 * WR * CT, 2)
 void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64 *__restrict__ theirs, int bstride,
                           const int32_t *__restrict__ leaf_slot, const int32_t *__restrict__ n_leaf_p,
                           float *__restrict__ out_p, float *__restrict__ out_v, int p_stride, int v_stride) {
     constexpr int CELLS = G::CELLS, COLS = G::COLS, ROWS = G::ROWS, A = G::A;
-    constexpr int MT = 8 / WR, WAVES = WR * CT, NTHREADS = 64 * WAVES;
+    constexpr int F16_ROWS = NR;                                 // (shadows the file-level constant: this workgroup's rows)
+    constexpr int MT = NR / 32 / WR, WAVES = WR * CT, NTHREADS = 64 * WAVES;
+    static_assert(MT >= 1 && MT * WR * 32 == NR, "the wave grid's row groups must tile the workgroup's rows");
     constexpr int TB = F16_ROWS / CELLS;
     constexpr int CP = 32 * CT, SL = CP / 16, RS = CP + 8;       // row stride in halves
     constexpr int ROW_BYTES = RS * 2, PLANE_BYTES = (F16_ROWS + 1) * ROW_BYTES, ZERO_BYTE = F16_ROWS * ROW_BYTES;
@@ -322,7 +329,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     STAMP16(0);
 
     for (int i = tid; i < RS; i += NTHREADS) { act_hi[F16_ROWS * RS + i] = (_Float16)0; act_lo[F16_ROWS * RS + i] = (_Float16)0; }
-    for (int i = tid; i < F16_ROWS; i += NTHREADS) s_perm[i] = P.perm[i];
+    for (int i = tid; i < F16_ROWS; i += NTHREADS) s_perm[i] = NR == 256 ? P.perm[i] : i;
     __syncthreads();
 
     auto row_geom = [&](int g, uint32_t &vm, int &ab, int &r) {     // g = GEMM row; r = its board-cell row in LDS
@@ -420,7 +427,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     // ---- residual blocks ---------------------------------------------------------------------------------
     // 64 channels on the 2 x 2 wave grid: the statically scheduled tower (nine taps per layer, so the two weight
     // buffers swap roles from layer to layer: the layer's parity is a template parameter)
-    constexpr bool STATIC16 = (ABL & 7) == 0 && WR == 2 && (CT == 2 || CT == 4);
+    constexpr bool STATIC16 = (ABL & 7) == 0 && NR == 256 && WR == 2 && (CT == 2 || CT == 4);
     h8 wh[3][2], wl[3][2];
     if constexpr (STATIC16) {
 #pragma unroll
@@ -726,11 +733,12 @@ int resnet16_load(ResNet16Dev *n, const float *blob, size_t n_floats, hipStream_
     return 0;
 }
 
-template <int CT, int WR, int ABL = 0>
+template <int CT, int WR, int ABL = 0, int NR = 256>
 static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, int bstride, const int32_t *leaf_slot, const int32_t *n_leaf,
                      int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s,
                      hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     using G = Connect4;
+    constexpr int F16_ROWS = NR;
     constexpr int WAVES = WR * CT, RS = 32 * CT + 8, TB = F16_ROWS / G::CELLS;
     constexpr size_t planes = (size_t)2 * (F16_ROWS + 1) * RS * 2;
     constexpr size_t heads = ((size_t)F16_ROWS * HB_STRIDE + F16_ROWS * 8 + TB * 8) * 4;
@@ -741,7 +749,7 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, i
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward_f16<G, CT, WR, ABL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resnet_forward_f16<G, CT, WR, ABL, NR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done.fetch_or(bit, std::memory_order_release);
     }
@@ -749,8 +757,9 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, i
     const int cap = gate_hi != 0 && gate_hi < max_leaves ? gate_hi : max_leaves;
     const int grid = (cap + TB - 1) / TB;
     Net16Params Q = P;
-    Q.perm = P.perm + (size_t)(WR == 1 ? 0 : WR == 2 ? 1 : WR == 4 ? 2 : 3) * F16_ROWS;      // row order of this wave grid
-    hipExtLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR, ABL>), dim3(grid), dim3(64 * WAVES), lds, s, ev_start, ev_stop, 0, Q, mine, theirs,
+    Q.perm = P.perm + (size_t)(WR == 1 ? 0 : WR == 2 ? 1 : WR == 4 ? 2 : 3) * 256;           // row order of this wave grid (NR = 256 only)
+    Q.wg_flops = P.wg_flops * (NR / 256.0) * (NR == 256 ? 1.0 : 6.0 / 5.0);                   // (the smaller forms skip no taps)
+    hipExtLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR, ABL, NR>), dim3(grid), dim3(64 * WAVES), lds, s, ev_start, ev_stop, 0, Q, mine, theirs,
                           bstride, leaf_slot, n_leaf, out_p, out_v, p_stride, v_stride);
 }
 
@@ -762,11 +771,62 @@ double resnet16_wg_flops(const ResNet16Dev *n, double flops_per_board) {
     return 3.0 * (tower * (256.0 / cells) * (5.0 / 6.0) * (CP / C) * (CP / C) + (flops_per_board - tower) * 6.0);
 }
 
+// what a launch needs besides the network parameters
+struct Fwd16 {
+    const u64 *mine, *theirs;
+    int bstride;
+    const int32_t *leaf_slot, *n_leaf;
+    int max_leaves;
+    float *out_p, *out_v;
+    int p_stride, v_stride;
+    hipStream_t s;
+};
+template <int CT, int WR, int NR = 256, int ABL = 0>
+static void go16(Net16Params &P, const Fwd16 &a, int gate_lo, int gate_hi, hipEvent_t e0, hipEvent_t e1) {
+    P.gate = (gate_lo / 16) | ((gate_hi / 16) << 16);              // run only for list lengths in (lo, hi]; hi = 0: no upper end
+    launch16<CT, WR, ABL, NR>(P, a.mine, a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.max_leaves, a.out_p, a.p_stride, a.out_v, a.v_stride,
+                              a.s, e0, e1);
+    P.gate = 0;
+}
+
+// 64 / 128 channels: ONE board per workgroup (64 rows) up to g_one boards, three (128 rows) up to g_mid, six beyond -- by the
+// launch's capacity, or, with the evaluation cache (by_count), by the list's length on the device: the forms whose range
+// starts below the capacity are all enqueued, each gated to its range (the timing events span the group of launches).
+template <int CT>
+static void forward_sized(Net16Params &P, const Fwd16 &a, bool by_count, hipEvent_t e0, hipEvent_t e1) {
+    // tuning knob AZSP_F16_GATES="a,b" (multiples of 16; the forms return the same bits)
+    static const int gate_env[2] = {[] { const char *x = getenv("AZSP_F16_GATES"); return x ? atoi(x) / 16 * 16 : -1; }(),
+                                    [] { const char *x = getenv("AZSP_F16_GATES"); const char *c = x ? strchr(x, ',') : nullptr; return c ? atoi(c + 1) / 16 * 16 : -1; }()};
+    // measured, stand-alone launches (round 3): 4 x 64: one board per workgroup 42-49 us up to 256 boards, 75 at 512, 105 at
+    // 768; three 72-81; six 78-86 up to 768 -> one up to 512, six beyond.  9 x 128: one 256-287 us up to 256, 441 at 512;
+    // three 372-398 up to 512, 475 at 768; six 465-504 up to 768, 550 at 1024 -> one up to 256, three up to 768, six beyond.
+    const int g_one = gate_env[0] >= 0 ? gate_env[0] : (CT >= 4 ? 256 : 512);
+    const int g_mid = gate_env[1] >= 0 ? (gate_env[1] > g_one ? gate_env[1] : g_one) : (CT >= 4 ? 768 : g_one);
+    const int cap = a.max_leaves;
+    // row groups of the small forms: every row group re-reads the column tile's weights, and a one-board workgroup has only
+    // its own 42 cells to amortise them over -- at 128 channels two row groups are 1.2 MB per layer from L2 (measured 443 us
+    // per 9 x 128 launch, as slow as the six-board form); one row group halves that.  (AZSP_F16_SMALL_WR overrides.)
+    static const int swr_env = [] { const char *x = getenv("AZSP_F16_SMALL_WR"); return x ? atoi(x) : 0; }();
+    const int swr = swr_env ? swr_env : (CT >= 4 ? 1 : 2);
+    auto one_form = [&](int lo, int hi, hipEvent_t x0, hipEvent_t x1) { if (swr == 1) go16<CT, 1, 64>(P, a, lo, hi, x0, x1); else go16<CT, 2, 64>(P, a, lo, hi, x0, x1); };
+    auto mid_form = [&](int lo, int hi, hipEvent_t x0, hipEvent_t x1) { go16<CT, 2, 128>(P, a, lo, hi, x0, x1); };      // (one row group measured no faster here)
+    if (!by_count) {
+        if (cap <= g_one) one_form(0, 0, e0, e1);
+        else if (cap <= g_mid) mid_form(0, 0, e0, e1);
+        else go16<CT, 2, 256>(P, a, 0, 0, e0, e1);
+        return;
+    }
+    const bool one = g_one > 0, mid = g_mid > g_one && cap > g_one, big = cap > g_mid;
+    const int last = big ? 2 : (mid ? 1 : 0);
+    if (one) one_form(0, cap > g_one ? g_one : 0, e0, last == 0 ? e1 : nullptr);
+    if (mid) mid_form(g_one, big ? g_mid : 0, one ? nullptr : e0, last == 1 ? e1 : nullptr);
+    if (big) go16<CT, 2, 256>(P, a, g_mid, 0, (one || mid) ? nullptr : e0, e1);
+}
+
 void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32_t *leaf_slot, const int32_t *n_leaf,
                       int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, bool by_count,
                       double *flop_acc, double wg_flops, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    (void)by_count;
-    const u64 *mine = leaf0, *theirs = leaf0 + Connect4::W;
+    Fwd16 a{leaf0, leaf0 + Connect4::W, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, p_stride, v_stride, s};
     Net16Params P;
     unsigned char *d = n->d_blob;
     auto H = [&](size_t o) { return reinterpret_cast<const h8 *>(d + o); };
@@ -782,17 +842,17 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
     P.flop_acc = flop_acc;
     P.wg_flops = wg_flops;
     P.gate = 0;
-    // wave grid WR x CT over the 256-row x C tile (tuning knob AZSP_F16_WR; results do not depend on it)
+    // wave grid WR x CT over the 256-row x C tile (tuning knob AZSP_F16_WR: forces the six-board form on that grid)
     static const int wr_env = [] { const char *e = getenv("AZSP_F16_WR"); return e ? atoi(e) : 0; }();
-#define L16(CTV, WRV) launch16<CTV, WRV>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s, ev_start, ev_stop)
     switch (n->CT) {
         case 1:
-            if (wr_env == 8 || (!wr_env && max_leaves <= 768)) L16(1, 8); else L16(1, 4);
+            if (wr_env == 8 || (!wr_env && max_leaves <= 768)) go16<1, 8>(P, a, 0, 0, ev_start, ev_stop);
+            else go16<1, 4>(P, a, 0, 0, ev_start, ev_stop);
             break;
         case 2: {
             bool print = false;
             if (resnet_trace_wanted(&print)) {     // diagnostic instantiation with the fp32 kernel's stamps: phase times, in-kernel clock
-                constexpr int TBB = F16_ROWS / Connect4::CELLS;
+                constexpr int TBB = 256 / Connect4::CELLS;
                 const int grid = (max_leaves + TBB - 1) / TBB;
                 unsigned long long *dd = nullptr;
                 const size_t cnt = (size_t)grid * 64;
@@ -800,7 +860,7 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
                     (void)hipMemsetAsync(dd, 0, cnt * 8, s);
                     Net16Params Q = P;
                     Q.dbg = dd;
-                    launch16<2, 2, 8>(Q, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s);
+                    go16<2, 2, 256, 8>(Q, a, 0, 0, nullptr, nullptr);
                     (void)hipStreamSynchronize(s);
                     std::vector<unsigned long long> h(cnt);
                     (void)hipMemcpy(h.data(), dd, cnt * 8, hipMemcpyDeviceToHost);
@@ -812,22 +872,25 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
 #ifdef AZSP_DIAG_BUILD   /* build.py --diag only (csrc/libazsp_diag.so): never part of the product library */
             static const int abl = [] { const char *e = getenv("AZSP_F16_ABLATE"); return e ? atoi(e) : 0; }();
             if (abl) {   // timing-only diagnostic builds (wrong results): 1 = no weight streaming, 2 = no LDS fragment traffic, 4 = no activation stores
-                if (abl == 1) launch16<2, 2, 1>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s);
-                else if (abl == 2) launch16<2, 2, 2>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s);
-                else if (abl == 3) launch16<2, 2, 3>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s);
-                else launch16<2, 2, 4>(P, mine, theirs, bstride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s);
+                if (abl == 1) go16<2, 2, 256, 1>(P, a, 0, 0, nullptr, nullptr);
+                else if (abl == 2) go16<2, 2, 256, 2>(P, a, 0, 0, nullptr, nullptr);
+                else if (abl == 3) go16<2, 2, 256, 3>(P, a, 0, 0, nullptr, nullptr);
+                else go16<2, 2, 256, 4>(P, a, 0, 0, nullptr, nullptr);
                 break;
             }
 #endif
-            // (by_count -- both wave grids enqueued, each gated to its range of list lengths -- measured slower than the one
-            // launch chosen by capacity: 9806 against 9992 episodes/s with the evaluation cache; the gate stays in the kernel)
-            if (wr_env == 4 || (!wr_env && max_leaves <= 768)) L16(2, 4); else L16(2, 2);   // small batch: more waves per board
+            if (wr_env == 4) go16<2, 4>(P, a, 0, 0, ev_start, ev_stop);
+            else if (wr_env == 2) go16<2, 2>(P, a, 0, 0, ev_start, ev_stop);
+            else forward_sized<2>(P, a, by_count, ev_start, ev_stop);
             break;
         }
-        case 3: L16(3, 2); break;
-        default: if (wr_env == 4) L16(4, 4); else L16(4, 2); break;
+        case 3: go16<3, 2>(P, a, 0, 0, ev_start, ev_stop); break;
+        default:
+            if (wr_env == 4) go16<4, 4>(P, a, 0, 0, ev_start, ev_stop);
+            else if (wr_env == 2) go16<4, 2>(P, a, 0, 0, ev_start, ev_stop);
+            else forward_sized<4>(P, a, by_count, ev_start, ev_stop);
+            break;
     }
-#undef L16
 }
 
 }  // namespace azsp
