@@ -28,7 +28,7 @@ class EpisodeGenerator:
         self.config = config
         self.device = device
         self.timing = timing
-        self.timing_sample = timing_sample    # timing=True: time only 8 of every 8 * timing_sample simulation rounds (0 / 1: all)
+        self.timing_sample = timing_sample    # timing=True: time only 32 of every 32 * timing_sample simulation rounds (0 / 1: all)
         # search options beyond the reference (None/off = reference behaviour): arg-max moves after
         # `sampling_plies` plies; gamma(alpha) root noise mixed in with weight `dirichlet_eps`, drawn per ply from
         # the global numpy RNG BEFORE the ply's uniforms (n_slots x n_actions values)

@@ -333,11 +333,12 @@ static int search_enqueue(azsp_engine *e, int n_act) {
         return 0;
     };
     auto ring_done = [&](int k) -> int { if (ring) HIP_TRY(hipEventRecord(e->ev_tree[k], e->gstream[k])); return 0; };
-    // AZSP_FLAG_TIMING with timing_sample = n > 1: events only in windows of 8 consecutive rounds out of every 8 n (the
+    // AZSP_FLAG_TIMING with timing_sample = n > 1: events only in windows of 32 consecutive rounds out of every 32 n (the
     // root stage counts as round 0): attaching timestamps to a dispatch costs a few microseconds of its own, which shows
-    // where a round is launch latency (evaluation cache, few games)
+    // where a round is launch latency (evaluation cache, few games).  (Long windows: where launches of several groups
+    // overlap, the union of a window's intervals misses the untimed neighbours at its two ends.)
     const int tsamp = e->cfg.timing_sample > 1 ? e->cfg.timing_sample : 1;
-    auto in_window = [&](int round) { return tsamp == 1 || (round % (8 * tsamp)) < 8; };
+    auto in_window = [&](int round) { return tsamp == 1 || (round % (32 * tsamp)) < 32; };
     e->timed_now = in_window(0);
     for (int k = 0; k < G; ++k) {
         hipStream_t st = e->gstream[k];
@@ -567,9 +568,10 @@ static int create_impl(azsp_engine *e) {
     // With a third of the evaluations a round no longer fills the machine twice over, so one group's launch leaves little
     // for a second group to overlap with: 3981 / 3595 / 3387 episodes/s (fp32), 7738 / 8070 / 8055 (f16x2).  With the ring of
     // tree steps (search_enqueue: a group may use what a lower group claimed in the same search) several groups reach
-    // 2.87 x / 2.85 x, but no more episodes/s than one (4005 / 4005 / 3792 fp32, 7720 / 7880 / 7554 f16x2): a round is one
-    // workgroup's latency either way.  One group unless the caller asks for more.
-    if (c.n_groups <= 0 && (c.flags & AZSP_FLAG_EVAL_CACHE)) e->n_groups = 1;
+    // 2.87 x / 2.85 x: 4321 / 4386 episodes/s with 1 / 2 groups (fp32), 9964 / 10659 / 10022 with 1 / 2 / 3 (f16x2, whose
+    // one- and three-board forms leave more of a round to the tree launch that a second group hides).  Two groups for large
+    // runs unless the caller says otherwise.
+    if (c.n_groups <= 0 && (c.flags & AZSP_FLAG_EVAL_CACHE)) e->n_groups = c.n_slots >= 1024 ? 2 : 1;
     for (int k = 1; k < e->n_groups; ++k) {
         HIP_TRY(hipStreamCreateWithFlags(&e->gstream[k], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));

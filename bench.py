@@ -218,7 +218,7 @@ def main() -> None:
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the in-kernel clock measurement after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timing-sample", type=int, default=4,
-                    help="evaluation-cache runs: HIP events around the kernels of 8 consecutive simulation rounds out of every 8 * N "
+                    help="evaluation-cache runs: HIP events around the kernels of 32 consecutive simulation rounds out of every 32 * N "
                          "(1 = every launch, as the runs without the cache always do)")
     ap.add_argument("--no-eval-cache", action="store_true", help="skip the evaluation-cache measurements")
     ap.add_argument("--eval-cache-headline", action="store_true", help="diagnostics: make the evaluation-cache run the top-level line")
@@ -290,9 +290,9 @@ def main() -> None:
         else:
             gen = azsp.EpisodeGenerator(game=game_cls(), config=cfg, device=local_rank, timing=True, n_groups=args.groups,
                                         f16_split=precision == "f16x2", eval_cache=eval_cache,
-                                        # sampled event windows only where launches do not overlap (one slot group): with
-                                        # three groups the union of a window's intervals misses its untimed neighbours
-                                        timing_sample=args.timing_sample if eval_cache and args.groups <= 1 else 1)
+                                        # sampled event windows for the cache runs only (a round there is launch latency);
+                                        # the runs without the cache time every launch
+                                        timing_sample=args.timing_sample if eval_cache else 1)
 
         def step(seed: int):
             if rehearse:
@@ -334,9 +334,10 @@ def main() -> None:
                     "episodes": episodes, "samples": samples, "ranks": ranks, "roofline": None, "tree": None}
         eng.close()
         launches = max(int(st["infer_launches"]), 1)
-        # The events sit on the launches of 8 consecutive simulation rounds out of every 8 * --timing-sample (timestamps on
-        # a dispatch cost a few microseconds each -- 5-9 % of the step where a round is launch latency); durations and
-        # overlap are measured on those launches and the busy time scaled to all of them.
+        # Evaluation-cache runs: the events sit on the launches of 32 consecutive simulation rounds out of every 32 *
+        # --timing-sample (timestamps on a dispatch cost a few microseconds each -- 5-9 % of the step where a round is launch
+        # latency); durations and overlap are measured on those launches and the busy time scaled to all of them (the union
+        # of a window's intervals misses the untimed neighbours at its two ends: with two groups ~1 % too much busy time).
         timed = max(int(st["infer_launches_timed"]), 1)
         avg_ms = st["infer_ms"] / timed
         # Launches of different slot groups run concurrently on separate streams, so the rate is taken over the

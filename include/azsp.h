@@ -114,8 +114,8 @@ typedef struct azsp_config {
     int32_t  search_rules;   /* AZSP_RULES_*                                                           */
     int32_t  eval_cache_entries; /* AZSP_FLAG_EVAL_CACHE: table entries (64 B each, rounded up to a power of two,
                                     at most 2^26); 0 = automatic (64 * n_slots * (n_sims + 1))              */
-    int32_t  timing_sample;  /* AZSP_FLAG_TIMING: n > 1 = time the kernels of 8 consecutive simulation rounds out of
-                                every 8 n only (timestamps on a dispatch cost a few microseconds each, which
+    int32_t  timing_sample;  /* AZSP_FLAG_TIMING: n > 1 = time the kernels of 32 consecutive simulation rounds out of
+                                every 32 n only (timestamps on a dispatch cost a few microseconds each, which
                                 matters where a round is launch latency); 0 / 1 = every launch            */
     int32_t  reserved;       /* 0                                                                      */
 } azsp_config;
