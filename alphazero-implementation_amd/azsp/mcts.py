@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 from .engine import Engine, game_id_of
-from .weights import is_resnet_state_dict, resnet_blob
+from .weights import is_resnet_state_dict, resnet_blob, resnet_geometry
 
 
 class Node:
@@ -70,7 +70,7 @@ def engine_geometry_for_model(model, game=None) -> tuple[int, int, int]:
     if game is not None and game_id_of(game) not in (0, 2):
         return 0, 0, 0
     if sd is not None and is_resnet_state_dict(sd):
-        _, blocks, ch = resnet_blob(sd)
+        blocks, ch = resnet_geometry(sd)
         if 1 <= (ch + 31) // 32 <= 8:
             return blocks, ch, 0
     return 0, 0, 0

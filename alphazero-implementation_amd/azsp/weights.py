@@ -25,6 +25,29 @@ def is_resnet_state_dict(sd) -> bool:
     return all(k in sd for k in ("input_conv.0.weight", "policy_head.4.weight", "value_head.4.weight"))
 
 
+def resnet_geometry(sd) -> tuple[int, int]:
+    """(num_res_blocks, num_channels) read off the state_dict's keys and shapes (no tensor is copied)."""
+    blocks = 0
+    while f"residual_blocks.{blocks}.conv1.weight" in sd:
+        blocks += 1
+    return blocks, int(sd["input_conv.0.weight"].shape[0])
+
+
+def weights_fingerprint(model):
+    """What decides whether the engine's copy of a torch module's weights is current: storage address and in-place version
+    counter of every parameter and buffer (optimizer steps, BatchNorm's running statistics and load_state_dict all bump
+    the counters; a deep copy has new storage).  Writes through `.data` or `set_()` are invisible to it: call the
+    generator's `invalidate_device_weights()` after such an update.  None for models that are not torch modules (their
+    weights are exported on every call)."""
+    params, buffers = getattr(model, "parameters", None), getattr(model, "buffers", None)
+    if not callable(params) or not callable(buffers):
+        return None
+    try:
+        return tuple((int(t.data_ptr()), int(t._version)) for t in list(params()) + list(buffers()))
+    except (AttributeError, RuntimeError, TypeError):
+        return None
+
+
 def resnet_blob(model_or_state_dict) -> tuple[np.ndarray, int, int]:
     """Returns (blob float32[n], num_res_blocks, num_channels)."""
     sd = model_or_state_dict if isinstance(model_or_state_dict, dict) else model_or_state_dict.state_dict()

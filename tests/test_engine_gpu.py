@@ -1196,3 +1196,56 @@ def test_eval_cache_edge_cases(azsp):
     # 5. no 64-bit key for 9x9 boards
     with pytest.raises(AzspError, match="EVAL_CACHE"):
         _engine(azsp, "gomoku9", 8, 10, eval_cache=True)
+
+
+def test_generator_reuploads_weights_exactly_when_they_changed(azsp, monkeypatch):
+    """generate_episodes exports and uploads the model's weights only when they changed since its last call (storage
+    address + in-place version of every tensor, bound to the model object): an optimizer-style in-place update, a
+    load_state_dict, another model object -- also one that reuses a freed model's memory -- and invalidate_device_weights()
+    all trigger the upload; a second call on untouched weights does not; and the episodes are those of a fresh generator."""
+    import copy
+    import torch
+    from azsp import mcts as M
+    calls = []
+    real = M.configure_engine_for_model
+    monkeypatch.setattr("azsp.episode_generator.configure_engine_for_model", lambda e, m: (calls.append(id(e)), real(e, m))[1])
+    torch.manual_seed(3)
+    net = azsp.ResNet((6, 7), 7, 2, 32).eval()
+    cfg = azsp.AlphaZeroConfig(32, 1, 10, 24, 1, 1)
+    gen = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg)
+
+    def run(model, seed=5):
+        np.random.seed(seed)
+        return list(gen.generate_episodes(model))
+
+    def fresh(model, seed=5):                                       # (its own engine: its upload is not counted)
+        before = list(calls)
+        np.random.seed(seed)
+        out = list(azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=cfg).generate_episodes(model))
+        calls[:] = before
+        return out
+    a = run(net)
+    assert len(calls) == 1
+    assert run(net) == a and len(calls) == 1                        # untouched weights: no export
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.01 * torch.randn_like(p))                      # what an optimizer step does
+    b = run(net)
+    n_fresh = len(calls)
+    assert n_fresh == 2 and b == fresh(net) and b != a
+    calls.clear()
+    net.load_state_dict(copy.deepcopy(net.state_dict()))
+    run(net)
+    assert len(calls) == 1
+    clone = copy.deepcopy(net)                                      # the reference's get_inference_clone
+    assert run(clone) == b and len(calls) == 2
+    del clone
+    torch.manual_seed(9)
+    other = azsp.ResNet((6, 7), 7, 2, 32).eval()                    # may land on the freed clone's addresses, versions 0
+    c = run(other)
+    assert len(calls) == 3 and c == fresh(other)
+    with torch.no_grad():
+        other.value_head[4].bias.data.add_(0.5)                     # a write the version counters do not see
+    gen.invalidate_device_weights()
+    d = run(other)
+    assert len(calls) == 4 and d == fresh(other)
