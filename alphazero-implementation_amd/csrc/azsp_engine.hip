@@ -337,8 +337,11 @@ static int search_enqueue(azsp_engine *e, int n_act) {
     // root stage counts as round 0): attaching timestamps to a dispatch costs a few microseconds of its own, which shows
     // where a round is launch latency (evaluation cache, few games).  (Long windows: where launches of several groups
     // overlap, the union of a window's intervals misses the untimed neighbours at its two ends.)
+    // The windows run over ALL rounds of the engine's life, not per search: the first rounds of a ply meet more known positions
+    // than its last ones (with the evaluation cache), so a window that always sat at a ply's start would not be representative.
     const int tsamp = e->cfg.timing_sample > 1 ? e->cfg.timing_sample : 1;
-    auto in_window = [&](int round) { return tsamp == 1 || (round % (32 * tsamp)) < 32; };
+    const uint64_t round0 = e->rounds_host;
+    auto in_window = [&](int round) { return tsamp == 1 || ((round0 + (uint64_t)round) % (uint64_t)(32 * tsamp)) < 32; };
     e->timed_now = in_window(0);
     for (int k = 0; k < G; ++k) {
         hipStream_t st = e->gstream[k];
