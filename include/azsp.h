@@ -94,8 +94,9 @@ enum { AZSP_OK = 0, AZSP_ERR_ARG = -1, AZSP_ERR_HIP = -2, AZSP_ERR_STATE = -3, A
  *   no_fused_rounds  runs of up to 32 games use the two-launch simulation rounds of larger runs instead of the one-launch
  *                    form (same results; the tests compare the two)
  *   unfused_tree     device evaluators use the four-launch slot-ordered rounds of the host evaluator (same results)
- * Nothing else in the product library reads the environment except AZSP_RESNET_VARIANT / AZSP_F16_WR (kernel-variant
- * choice among variants that return the same bits) and AZSP_RESNET_TRACE / AZSP_PROBE_VERBOSE (phase-time printouts). */
+ * Nothing else in the product library reads the environment except tuning knobs that choose among kernel variants which
+ * return the same bits (AZSP_RESNET_VARIANT, AZSP_RESNET_GATES, AZSP_F16_WR, AZSP_F16_SMALL_WR, AZSP_F16_GATES) and
+ * AZSP_RESNET_TRACE / AZSP_PROBE_VERBOSE (phase-time printouts). */
 
 typedef struct azsp_config {
     uint32_t struct_size;    /* sizeof(azsp_config), for forward compatibility                       */

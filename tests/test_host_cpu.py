@@ -312,3 +312,30 @@ def test_gen1_records_json_and_model_surface():
         gen1.Model()                       # abstract: predict must be provided  (models/base/model.py:54)
     with pytest.raises(NotImplementedError):
         gen1._check_connect4(cs.Config(5, 5, 3).sample_initial_state())
+
+
+def test_ctypes_structures_match_the_header(tmp_path):
+    """The Python binding restates azsp_config / azsp_stats / azsp_ply_result / azsp_search_options field by field: their
+    sizes and the offsets of their last fields must be what a C compiler makes of include/azsp.h (ABI drift would
+    otherwise only show on a GPU box, as a struct_size refusal or, for the stats, as silently shifted numbers)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "sz.c"
+    src.write_text('''#include <stdio.h>
+#include <stddef.h>
+#include "azsp.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(azsp_config), sizeof(azsp_stats), sizeof(azsp_ply_result), sizeof(azsp_search_options),
+           offsetof(azsp_config, timing_sample), offsetof(azsp_stats, infer_exec_flops), offsetof(azsp_stats, evals_executed));
+    return 0;
+}
+''')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    want = [C.sizeof(_lib.Config), C.sizeof(_lib.Stats), C.sizeof(_lib.PlyResult), C.sizeof(_lib.SearchOptions),
+            _lib.Config.timing_sample.offset, _lib.Stats.infer_exec_flops.offset, _lib.Stats.evals_executed.offset]
+    assert got == want, (got, want)
