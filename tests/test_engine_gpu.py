@@ -1193,7 +1193,16 @@ def test_eval_cache_edge_cases(azsp):
     second = list(g.generate_episodes(net2))
     fresh, _, _ = _run_gen(azsp, net2, 100, 30, 5)
     assert second == fresh
-    # 5. no 64-bit key for 9x9 boards
+    # 5. the search counter in the key word has 12 bits: after 4095 searches the table is cleared and the count restarts
+    small = np.stack(random_midgame_boards(rules, np.random.RandomState(8), 6, 12)).astype(np.int8)
+    with _engine(azsp, "connect4", 6, 3, hash_salt=2, eval_cache=True) as e:
+        e.use_hash_evaluator()
+        first = e.run_batch(small)
+        for i in range(4200):
+            out = e.run_batch(small)
+            if i % 500 == 0 or i > 4080:
+                assert all(np.array_equal(first[k], out[k]) for k in first), i
+    # 6. no 64-bit key for 9x9 boards
     with pytest.raises(AzspError, match="EVAL_CACHE"):
         _engine(azsp, "gomoku9", 8, 10, eval_cache=True)
 
