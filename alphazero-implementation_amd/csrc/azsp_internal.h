@@ -83,6 +83,7 @@ struct TreeGeo {
 // inference launch before the read.  A key claimed by a HIGHER group during the current search is not usable yet: the
 // game falls back to its private entry (a duplicate evaluation, same bits).
 struct alignas(64) EvalEnt { u64 key; u64 mine, theirs, pad; float row[8]; };   // row = p[0..A), value at [7]  (AP == 8 games)
+static_assert(sizeof(EvalEnt) == 64, "the inference kernels address entries with strides of 8 words / 16 floats");
 constexpr int EVAL_PROBES = 16;
 constexpr u64 EVAL_POS_MASK = (1ull << 49) - 1;
 

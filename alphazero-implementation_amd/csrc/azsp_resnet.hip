@@ -341,10 +341,13 @@ struct Variant {
     void (*launch)(const FwdArgs &);
     int perm_offset;                      // which row-order table of ResNetDev::d_perm the kernel expects
     int mt, pf, cw, rw;                   // the instantiation's row tiles per wave, prefetch form and wave grid (for the FLOP accounting)
+    int max_by_count = 0;                 // upper end of its range when the variant is chosen by list length (evaluation cache: two
+                                          // groups' launches in flight); 0 = max_boards
 };
 static const Variant VARIANTS[] = {
     {"c4_32_small", 0, 1, 768, fwd_c4_32_small, 0, 1, 1, 1, 4},   {"c4_32_big", 0, 1, INT_MAX, fwd_c4_32_big, 0, 2, 0, 1, 4},
-    {"c4_64_one", 0, 2, 512, fwd_c4_64_one, 0, 1, 2, 2, 2},       {"c4_64_mid", 0, 2, 768, fwd_c4_64_mid, 0, 2, 0, 2, 2},
+    {"c4_64_one", 0, 2, 512, fwd_c4_64_one, 0, 1, 2, 2, 2},
+    {"c4_64_mid", 0, 2, 768, fwd_c4_64_mid, 0, 2, 0, 2, 2, 1024},   // (by length up to 1024: 4380 -> 4475 episodes/s with the cache, three A/B rounds)
     {"c4_64_big", 0, 2, INT_MAX, fwd_c4_64_big, 256, 4, 0, 2, 2},
     {"c4_96", 0, 3, INT_MAX, fwd_c4_96, 0, 1, 1, 1, 4},
     {"c4_128_one", 0, 4, 512, fwd_c4_128_one, 0, 1, 2, 4, 2},     {"c4_128_mid", 0, 4, 768, fwd_c4_128_mid, 0, 2, 0, 4, 2},
@@ -499,7 +502,7 @@ static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_str
     for (const Variant &w : VARIANTS) {
         if (w.game != game || w.nt != n->g.NT) continue;
         if (prev >= max_leaves) break;
-        int hi = w.max_boards;
+        int hi = w.max_by_count > 0 ? w.max_by_count : w.max_boards;
         if (hi != INT_MAX && k < 2 && gate_env[k] >= 0) hi = gate_env[k];
         ++k;
         if (hi <= prev) continue;                        // an empty range: this variant is never the one
