@@ -86,6 +86,31 @@ static void build_row_order(int32_t *perm) {
         for (int i = 0; i < 32; ++i) perm[w * 64 + i] = (*special[w])[i];
         for (int i = 0; i < 32; ++i) perm[w * 64 + 32 + i] = interior[w * 32 + i];
     }
+    // third table (at 512): THREE boards in eight 16-row tiles for t16m_layer: 0 = left column (12 non-corner cells + the
+    // top-left and bottom-left corners of boards 0 and 1), 1 = 16 right-column cells, 2 = the 15 inner cells of the top rows
+    // + board 2's top-left corner, 3 = the same at the bottom, 4..7 = the 60 interior cells, the two right-column cells left
+    // over and the padding rows 126, 127
+    {
+        std::vector<int> l16, r16, t16, b16, in16;
+        for (int b = 0; b < 3; ++b)
+            for (int y = 0; y < R; ++y)
+                for (int x = 0; x < C; ++x) {
+                    const int r = b * CE + y * C + x;
+                    if (x == 0) {
+                        if ((y == 0 || y == R - 1) && b == 2) (y == 0 ? t16 : b16).push_back(r);
+                        else l16.push_back(r);
+                    } else if (x == C - 1) {
+                        if (r16.size() < 16) r16.push_back(r); else in16.push_back(r);
+                    } else if (y == 0) t16.push_back(r);
+                    else if (y == R - 1) b16.push_back(r);
+                    else in16.push_back(r);
+                }
+        in16.push_back(126);
+        in16.push_back(127);
+        int32_t *m = perm + 512;
+        for (int i = 0; i < 16; ++i) { m[i] = l16[i]; m[16 + i] = r16[i]; m[32 + i] = t16[i]; m[48 + i] = b16[i]; }
+        for (int i = 0; i < 64; ++i) m[64 + i] = in16[i];
+    }
     // second table: 2 x 2 wave grid, a row group = 4 row tiles: [left, right, interior, interior | top, bottom, interior, interior]
     int32_t *q = perm + 256;
     for (int grp = 0; grp < 2; ++grp) {
@@ -134,7 +159,7 @@ ResNetDev *resnet_create(int game, int blocks, int channels, bool f16_split) {
         (void)hipFree(n->d_blob); delete n; return nullptr;
     }
     if (game == 0) {
-        int32_t perm[512];
+        int32_t perm[640];
         build_row_order(perm);
         if (hipMalloc((void **)&n->d_perm, sizeof perm) != hipSuccess ||
             hipMemcpy(n->d_perm, perm, sizeof perm, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(n->d_blob); delete n; return nullptr; }
@@ -347,10 +372,10 @@ struct Variant {
 static const Variant VARIANTS[] = {
     {"c4_32_small", 0, 1, 768, fwd_c4_32_small, 0, 1, 1, 1, 4},   {"c4_32_big", 0, 1, INT_MAX, fwd_c4_32_big, 0, 2, 0, 1, 4},
     {"c4_64_one", 0, 2, 512, fwd_c4_64_one, 0, 1, 2, 2, 2},
-    {"c4_64_mid", 0, 2, 768, fwd_c4_64_mid, 0, 2, 0, 2, 2, 1024},   // (by length up to 1024: 4380 -> 4475 episodes/s with the cache, three A/B rounds)
+    {"c4_64_mid", 0, 2, 768, fwd_c4_64_mid, 512, 2, 3, 2, 2, 1024},   // (by length up to 1024: 4380 -> 4475 episodes/s with the cache, three A/B rounds)
     {"c4_64_big", 0, 2, INT_MAX, fwd_c4_64_big, 256, 4, 0, 2, 2},
     {"c4_96", 0, 3, INT_MAX, fwd_c4_96, 0, 1, 1, 1, 4},
-    {"c4_128_one", 0, 4, 512, fwd_c4_128_one, 0, 1, 2, 4, 2},     {"c4_128_mid", 0, 4, 768, fwd_c4_128_mid, 0, 2, 0, 4, 2},
+    {"c4_128_one", 0, 4, 512, fwd_c4_128_one, 0, 1, 2, 4, 2},     {"c4_128_mid", 0, 4, 768, fwd_c4_128_mid, 512, 2, 3, 4, 2},
     {"c4_128_big", 0, 4, INT_MAX, fwd_c4_128_big, 256, 4, 0, 4, 2},
     {"c4_192", 0, 6, INT_MAX, fwd_c4_192, 0, 2, 1, 3, 2},         {"c4_256", 0, 8, INT_MAX, fwd_c4_256, 0, 2, 1, 4, 2},
     {"g9_32", 2, 1, INT_MAX, fwd_g9_32, 0, 2, 0, 1, 4},           {"g9_64", 2, 2, INT_MAX, fwd_g9_64, 0, 2, 0, 1, 4},
@@ -378,7 +403,7 @@ static double variant_wg_flops(const ResNetDev *n, const Variant *v, int *boards
     const double rest = n->flops_per_board - tower;
     const double pad_ch = ((double)g.Cp / C) * ((double)g.Cp / C);
     const int wg_rows = v->rw * 32 * v->mt, tb = wg_rows / g.cells;
-    const bool sk = v->game == 0 && v->pf == 0 && ((v->mt == 2 && v->rw == 4) || (v->mt == 4 && v->rw == 2 && v->cw == v->nt));
+    const bool sk = v->game == 0 && ((v->pf == 0 && ((v->mt == 2 && v->rw == 4) || (v->mt == 4 && v->rw == 2 && v->cw == v->nt))) || v->pf == 3);
     const bool tile16 = v->game == 2 && v->pf == 0 && v->cw == v->nt && v->rw == 1 && v->mt == 3 && v->nt >= 3;
     const bool tile16c = v->game == 0 && v->pf == 2;                    // one Connect-4 board on three 16-row tiles
     const double rows = tile16 ? cells * tb : (tile16c ? 48.0 : (double)wg_rows);      // GEMM rows the workgroup computes

@@ -583,6 +583,71 @@ __device__ __forceinline__ void conv_tile16c(f32x4m (&acc)[NRT], const float *ac
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 16-row tiles for THREE Connect-4 boards per workgroup, with static tap skipping (mid-size batches, and the workhorse of the
+// evaluation cache, whose launches hold a few hundred positions)
+// ------------------------------------------------------------------------------------------------
+// In 32-row tiles the 126 cells of three boards cannot skip taps (no class of cells that lack the same taps fills a tile);
+// in 16-row tiles they can: tile 0 = 16 left-column cells (lack dx = -1: 3 of 9 taps), 1 = 16 right-column cells, 2 = the 15
+// inner cells of the top rows + a top-left corner, 3 = the same at the bottom, 4..7 = interior cells, the two right-column
+// cells left over and two padding rows (build_row_order's third table).  60 of 72 tile-taps remain (the six-board kernels'
+// 5/6).  Which tile-taps exist is static, so a layer is ONE straight-line sequence of 60 x SPT steps (tile-tap x 16-channel
+// group, four v_mfma_f32_16x16x4_f32 each) as in tower_layer: step i issues the 16-byte activation read of step i + 2 (four
+// rotating buffers) and its own MFMAs; a tap's last tile reloads each weight quad for the next tap right after using it.
+// Same slot order and weights as conv_tile16c; same bits as every other variant.
+struct T16Step { int tap, tile, q, last; };
+__host__ __device__ constexpr bool t16m_needs(int tile, int tap) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    return tile == 0 ? dx != -1 : (tile == 1 ? dx != 1 : (tile == 2 ? dy != -1 : (tile == 3 ? dy != 1 : true)));
+}
+template <int SPT>
+struct T16MSched {
+    static constexpr int NSTEP = 60 * SPT;
+    T16Step s[NSTEP + 2];
+    constexpr T16MSched() : s{} {
+        int n = 0;
+        for (int tap = 0; tap < 9; ++tap) {
+            int last_tile = 0;
+            for (int tile = 0; tile < 8; ++tile) if (t16m_needs(tile, tap)) last_tile = tile;
+            for (int tile = 0; tile < 8; ++tile) {
+                if (!t16m_needs(tile, tap)) continue;
+                for (int q = 0; q < SPT; ++q) { s[n].tap = tap; s[n].tile = tile; s[n].q = q; s[n].last = tile == last_tile; ++n; }
+            }
+        }
+        s[n] = s[n - 1]; s[n + 1] = s[n - 1];          // the reads past the end repeat the last one
+    }
+};
+template <int SPT>
+struct T16MHolder { static constexpr T16MSched<SPT> SC{}; };
+
+template <class G, int SPT, int NT, int STRIDE, int I>
+__device__ __forceinline__ void t16m_step(f32x4m (&acc)[8], const float *act, const int (&rix)[8], const uint32_t (&vmk)[8], int zero_idx,
+                                          const float *wq, float4 (&wb)[SPT], float4 (&xa)[4], int &rbase) {
+    constexpr T16Step st = T16MHolder<SPT>::SC.s[I], nx = T16MHolder<SPT>::SC.s[I + 2];
+    constexpr size_t QSTR = (size_t)2 * NT * 64 * 4;                  // floats between consecutive 16-channel input groups
+    if constexpr (nx.q == 0 && I + 2 < T16MSched<SPT>::NSTEP)         // step i + 2 opens a new (tile, tap) block
+        rbase = tower_aindex<G, STRIDE>(rix[nx.tile], vmk[nx.tile], nx.tap, zero_idx);
+    xa[(I + 2) % 4] = *reinterpret_cast<const float4 *>(act + rbase + 16 * nx.q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[st.tile] = conv_mma16(f4c(xa[I % 4], k), f4c(wb[st.q], k), acc[st.tile]);
+    if constexpr (st.last != 0)                                       // the next tap's (past the layer's end: the next layer's) group q
+        wb[st.q] = *reinterpret_cast<const float4 *>(wq + (size_t)((st.tap + 1) * SPT + st.q) * QSTR);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I + 1 < T16MSched<SPT>::NSTEP) t16m_step<G, SPT, NT, STRIDE, I + 1>(acc, act, rix, vmk, zero_idx, wq, wb, xa, rbase);
+}
+template <class G, int SPT, int NT, int STRIDE>
+__device__ __forceinline__ void t16m_layer(f32x4m (&acc)[8], const float *act, const int (&rix)[8], const uint32_t (&vmk)[8], int zero_idx,
+                                           const float *wq, float4 (&wb)[SPT]) {
+    constexpr T16Step s0 = T16MHolder<SPT>::SC.s[0], s1 = T16MHolder<SPT>::SC.s[1];
+    float4 xa[4];
+    int rbase = tower_aindex<G, STRIDE>(rix[s0.tile], vmk[s0.tile], s0.tap, zero_idx);
+    xa[0] = *reinterpret_cast<const float4 *>(act + rbase + 16 * s0.q);
+    if constexpr (s1.q == 0) rbase = tower_aindex<G, STRIDE>(rix[s1.tile], vmk[s1.tile], s1.tap, zero_idx);
+    xa[1] = *reinterpret_cast<const float4 *>(act + rbase + 16 * s1.q);
+    __builtin_amdgcn_sched_barrier(0);
+    t16m_step<G, SPT, NT, STRIDE, 0>(acc, act, rix, vmk, zero_idx, wq, wb, xa, rbase);
+}
+
 // (C/D layout of v_mfma_f32_32x32x2_f32: register v of lane l holds row (v & 3) + 8 * (v >> 2) + 4 * (l >> 5), column
 // l & 31 -- with the weights on the A side the row is the output channel and the column the board cell: conv_mma above)
 
@@ -611,8 +676,11 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     // wave owns one 16-channel output tile
     constexpr bool TILE16C = std::is_same<G, Connect4>::value && PF == 2;
     static_assert(!TILE16C || (MT == 1 && WG_ROWS / CELLS == 1 && RW * CW * 16 == 32 * NT), "one board, one 16-channel tile per wave");
-    constexpr int PFE = PF == 2 ? 0 : PF;          // (the prefetch form of the other convolutions)
-    constexpr bool ROLLED = !STATIC_TOWER && !TILE16 && !TILE16C && PF == 0 && CW == NT && NT >= 2;
+    // three Connect-4 boards per workgroup on eight 16-row tiles with static tap skipping (t16m_layer): PF == 3
+    constexpr bool TILE16M = std::is_same<G, Connect4>::value && PF == 3;
+    static_assert(!TILE16M || (MT == 2 && WG_ROWS == 128 && RW * CW * 16 == 32 * NT), "three boards, one 16-channel tile per wave");
+    constexpr int PFE = PF >= 2 ? 0 : PF;          // (the prefetch form of the other convolutions)
+    constexpr bool ROLLED = !STATIC_TOWER && !TILE16 && !TILE16C && !TILE16M && PF == 0 && CW == NT && NT >= 2;
     constexpr int WBN = ROLLED ? RolledGeo<S / 4>::QC : 8;
     constexpr int SPT16 = CP / 16, QC16 = Tile16Geo<SPT16>::QC;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -799,9 +867,11 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
 #pragma unroll
         for (int j = 0; j < WBN; ++j) wb[j] = *reinterpret_cast<const float4 *>(wq0 + (size_t)j * NT * 64 * 4);
     }
-    if constexpr (TILE16C) {
-        // ---- the whole tower on three 16-row tiles (cells 0..47: 42 real), activations in slot order ----
-        constexpr int CP16 = CP / 4, ITEMS = 48 * CP16, PER = (ITEMS + NTHREADS - 1) / NTHREADS;
+    if constexpr (TILE16C || TILE16M) {
+        // ---- the whole tower on 16-row tiles, activations in slot order: ONE board = three tiles (cells 0..47, 42 real;
+        //      conv_tile16c) or THREE boards = eight tiles in the tap-skipping order of P.perm (t16m_layer) ----
+        constexpr int NRT = TILE16C ? 3 : 8, TROWS = 16 * NRT;
+        constexpr int CP16 = CP / 4, ITEMS = TROWS * CP16, PER = (ITEMS + NTHREADS - 1) / NTHREADS;
         const int nl = 2 * P.blocks;
         if (nl > 0) {
             float4 mv[PER];
@@ -819,52 +889,55 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
             }
             __syncthreads();
             const int c16 = 16 * (tid >> 6);            // this wave's 16-channel output tile (slots c16 .. c16 + 15)
-            int rix[3];
-            uint32_t vmk[3];
-            f32x4m a16[3], xr16[3];
+            int rix[NRT];
+            uint32_t vmk[NRT];
+            f32x4m a16[NRT], xr16[NRT];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int pos = 16 * t + l15, y = pos / COLS, x = pos % COLS;
+            for (int t = 0; t < NRT; ++t) {
+                const int r = TILE16C ? 16 * t + l15 : P.perm[16 * t + l15];        // board-cell row of this lane's cell
+                const int b = r / CELLS, pos = r % CELLS, y = pos / COLS, x = pos % COLS;
                 uint32_t m = 0;
-                if (pos < CELLS && board0 < n_leaf)
+                if (r < TB * CELLS && board0 + b < n_leaf)
                     for (int tp = 0; tp < 9; ++tp) {
                         const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
                         if (yy >= 0 && yy < ROWS && xx >= 0 && xx < COLS) m |= 1u << tp;
                     }
                 vmk[t] = m;
-                rix[t] = pos * STRIDE + 4 * kq;
+                rix[t] = r * STRIDE + 4 * kq;
             }
             {   // block input + the bias of the block's second convolution, from what the stem stored
                 const float4 bq = *reinterpret_cast<const float4 *>(P.conv_b16 + (size_t)P.conv_b_stride + c16 + 4 * kq);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < NRT; ++t) {
                     const float4 x = *reinterpret_cast<const float4 *>(act + rix[t] + c16);
                     xr16[t] = (f32x4m){x.x + bq.x, x.y + bq.y, x.z + bq.z, x.w + bq.w};
                 }
             }
-            float4 wbc[QC16];
+            constexpr int NWB = TILE16C ? QC16 : SPT16;       // weight quads in registers: a chunk (one board) or a whole tap (three)
+            float4 wbc[NWB];
             const float *wq0 = P.conv_w16 + ((size_t)(tid >> 6) * 64 + lane) * 4;
 #pragma unroll
-            for (int j = 0; j < QC16; ++j) wbc[j] = *reinterpret_cast<const float4 *>(wq0 + (size_t)j * 2 * NT * 64 * 4);
+            for (int j = 0; j < NWB; ++j) wbc[j] = *reinterpret_cast<const float4 *>(wq0 + (size_t)j * 2 * NT * 64 * 4);
             for (int layer = 0; layer < nl; ++layer) {
                 const bool second = layer & 1;
                 const float *blc = P.conv_b16 + (size_t)layer * P.conv_b_stride + c16;
                 const bool fold = second && layer + 2 < nl;        // a next block exists: keep its input + bias
                 if (second) {
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) a16[t] = xr16[t];
+                    for (int t = 0; t < NRT; ++t) a16[t] = xr16[t];
                 } else {
                     const float4 bq = *reinterpret_cast<const float4 *>(blc + 4 * kq);
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) a16[t] = (f32x4m){bq.x, bq.y, bq.z, bq.w};
+                    for (int t = 0; t < NRT; ++t) a16[t] = (f32x4m){bq.x, bq.y, bq.z, bq.w};
                 }
-                conv_tile16c<G, 3, SPT16, NT, STRIDE>(a16, act, rix, vmk, ZERO_IDX + 4 * kq, wq0 + (size_t)layer * P.conv_w_stride, wbc);
+                if constexpr (TILE16C) conv_tile16c<G, 3, SPT16, NT, STRIDE>(a16, act, rix, vmk, ZERO_IDX + 4 * kq, wq0 + (size_t)layer * P.conv_w_stride, wbc);
+                else t16m_layer<G, SPT16, NT, STRIDE>(a16, act, rix, vmk, ZERO_IDX + 4 * kq, wq0 + (size_t)layer * P.conv_w_stride, wbc);
                 if (layer < 16) STAMP(3 + 3 * layer);
                 float4 b2q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (fold) b2q = *reinterpret_cast<const float4 *>(blc + 2 * (size_t)P.conv_b_stride + 4 * kq);
                 __syncthreads();                           // every wave is done reading the layer input
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < NRT; ++t) {
                     const float4 o = make_float4(relu(a16[t][0]), relu(a16[t][1]), relu(a16[t][2]), relu(a16[t][3]));
                     *reinterpret_cast<float4 *>(act + rix[t] + c16) = o;
                     if (fold) xr16[t] = (f32x4m){o.x + b2q.x, o.y + b2q.y, o.z + b2q.z, o.w + b2q.w};
