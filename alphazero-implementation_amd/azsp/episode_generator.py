@@ -8,7 +8,6 @@ the GPU: per ply the host only draws the uniforms the reference would draw from 
 RNG (one per slot, slot order) and collects the episodes that finished."""
 from __future__ import annotations
 
-import weakref
 from typing import Generator
 
 import numpy as np
@@ -16,8 +15,7 @@ import numpy as np
 from .config import AlphaZeroConfig
 from .engine import Engine
 from .episode import Episode, Sample
-from .mcts import configure_engine_for_model, default_device, engine_geometry_for_model
-from .weights import weights_fingerprint
+from .mcts import WeightsOnDevice, default_device, engine_geometry_for_model
 
 
 class EpisodeGenerator:
@@ -48,14 +46,13 @@ class EpisodeGenerator:
         self.n_groups = n_groups      # concurrent slot groups (HIP streams); 0 = automatic; never changes results
         self._engine: Engine | None = None
         self._engine_key = None
-        self._weights_fp = None       # fingerprint of the weights the engine holds (weights_fingerprint), None = unknown
-        self._weights_of = None       # weak reference to the model they came from (a freed model's addresses get reused)
+        self._weights = WeightsOnDevice()     # which model's weights the engine holds (re-exported only when they changed)
         self.last_stats: dict | None = None
 
     def invalidate_device_weights(self) -> None:
         """Force the next generate_episodes call to export and upload the model's weights again (needed only after
         updates that by-pass the tensors' version counters: writes through `.data`, `set_()`)."""
-        self._weights_fp = None
+        self._weights.invalidate()
 
     def engine_for(self, model) -> Engine:
         blocks, ch, salt = engine_geometry_for_model(model, self.game)
@@ -72,18 +69,10 @@ class EpisodeGenerator:
                                   eval_cache=self.eval_cache, eval_cache_entries=self.eval_cache_entries,
                                   timing_sample=self.timing_sample)
             self._engine_key = key
-            self._weights_fp = None
-        # The weights are exported (22 ms for 4 x 64: 142 tensors) and uploaded again only when the model changed since the
-        # last call -- every training iteration does, a second call on the same weights does not.
-        fp = weights_fingerprint(model)
-        same_model = self._weights_of is not None and self._weights_of() is model
-        if fp is None or not same_model or fp != self._weights_fp:
-            configure_engine_for_model(self._engine, model)
-            self._weights_fp = fp
-            try:
-                self._weights_of = weakref.ref(model)
-            except TypeError:               # (objects without weak references: exported every time)
-                self._weights_of = None
+            self._weights.invalidate()          # a new engine holds no weights (and may reuse the old one's id)
+        # The weights are exported and uploaded again only when the model changed since the last call -- every training
+        # iteration does, a second call on the same weights does not.
+        self._weights.ensure(self._engine, model)
         return self._engine
 
     def generate_episodes(self, model) -> Generator[Episode, None, None]:

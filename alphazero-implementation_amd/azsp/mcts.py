@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 from .engine import Engine, game_id_of
-from .weights import is_resnet_state_dict, resnet_blob, resnet_geometry
+import weakref
+
+from .weights import is_resnet_state_dict, resnet_blob, resnet_geometry, weights_fingerprint
 
 
 class Node:
@@ -60,6 +62,32 @@ def configure_engine_for_model(engine: Engine, model) -> None:
     engine.use_host_evaluator(model.predict)
 
 
+class WeightsOnDevice:
+    """Remembers which model's weights an engine holds, so that they are exported (22 ms for 4 x 64: 142 tensors) and
+    uploaded again only when they changed: storage address + in-place version counter of every tensor
+    (`weights_fingerprint`), bound to the model object by a weak reference (a freed model's addresses get reused).  Models
+    that are not torch modules are configured on every call."""
+
+    def __init__(self):
+        self._fp = None
+        self._of = None
+        self._engine_id = None
+
+    def invalidate(self) -> None:
+        self._fp = None
+
+    def ensure(self, engine: Engine, model) -> None:
+        fp = weights_fingerprint(model)
+        same = self._of is not None and self._of() is model and self._engine_id == id(engine)
+        if fp is None or not same or fp != self._fp:
+            configure_engine_for_model(engine, model)
+            self._fp, self._engine_id = fp, id(engine)
+            try:
+                self._of = weakref.ref(model)
+            except TypeError:               # (objects without weak references: configured every time)
+                self._of = None
+
+
 def engine_geometry_for_model(model, game=None) -> tuple[int, int, int]:
     """(res_blocks, channels, hash_salt) to create an engine for this model.  The device network exists for
     Connect-4 (the reference's ResNet, resnet.py:30-157) and, with the same architecture, for the 9x9 Gomoku plugin;
@@ -81,11 +109,19 @@ def default_device() -> int:
 
 
 class MCTS:
-    def __init__(self, game, model, num_simulations: int):
+    def __init__(self, game, model, num_simulations: int, *, eval_cache: bool = False):
         self.game = game
         self.model = model
         self.num_simulations = num_simulations
+        # optional (not in the reference's signature): keep every evaluated position's (p, v) on the device across run_batch
+        # calls on the same weights -- same roots, fewer evaluations (AZSP_FLAG_EVAL_CACHE; device evaluators only)
+        self.eval_cache = eval_cache
         self._engine: Engine | None = None
+        self._weights = WeightsOnDevice()
+
+    def invalidate_device_weights(self) -> None:
+        """After weight updates that by-pass the tensors' version counters (writes through `.data`, `set_()`)."""
+        self._weights.invalidate()
 
     def _engine_for(self, n: int) -> Engine:
         if self._engine is None or self._engine.n_slots < n:
@@ -93,8 +129,9 @@ class MCTS:
                 self._engine.close()
             blocks, ch, salt = engine_geometry_for_model(self.model, self.game)
             self._engine = Engine(self.game, max(n, 64), self.num_simulations, device=default_device(),
-                                  res_blocks=blocks, channels=ch, hash_salt=salt)
-        configure_engine_for_model(self._engine, self.model)
+                                  res_blocks=blocks, channels=ch, hash_salt=salt, eval_cache=self.eval_cache)
+            self._weights.invalidate()          # a new engine holds no weights
+        self._weights.ensure(self._engine, self.model)
         return self._engine
 
     def run(self, state: np.ndarray, to_play: int) -> Node:

@@ -63,9 +63,10 @@ def test_run_batch_matches_reference_fixtures(azsp, cache):
             _check_run(e.run_batch(boards), run)        # again on the same engine (the cache now holds every position)
 
 
-def test_mcts_facade_matches_reference_fixtures(azsp):
+@pytest.mark.parametrize("cache", [False, True], ids=["nocache", "evalcache"])
+def test_mcts_facade_matches_reference_fixtures(azsp, cache):
     run = [r for r in load_json("search_hash.json")["runs"] if r["game"] == "connect4" and r["sims"] == 100][0]
-    mcts = azsp.MCTS(azsp.Connect4Game(), HashStub("connect4", run["salt"]), run["sims"])
+    mcts = azsp.MCTS(azsp.Connect4Game(), HashStub("connect4", run["salt"]), run["sims"], eval_cache=cache)
     roots = mcts.run_batch([np.array(b) for b in run["boards"]], run["to_plays"])
     for root, g in zip(roots, run["roots"]):
         assert root.visit_count == g["n"] and float(root.value_sum) == g["w"]
@@ -1217,7 +1218,7 @@ def test_generator_reuploads_weights_exactly_when_they_changed(azsp, monkeypatch
     from azsp import mcts as M
     calls = []
     real = M.configure_engine_for_model
-    monkeypatch.setattr("azsp.episode_generator.configure_engine_for_model", lambda e, m: (calls.append(id(e)), real(e, m))[1])
+    monkeypatch.setattr("azsp.mcts.configure_engine_for_model", lambda e, m: (calls.append(id(e)), real(e, m))[1])
     torch.manual_seed(3)
     net = azsp.ResNet((6, 7), 7, 2, 32).eval()
     cfg = azsp.AlphaZeroConfig(32, 1, 10, 24, 1, 1)
