@@ -1119,9 +1119,13 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
             const bool real = r < TB * CELLS && board0 + r / CELLS < n_leaf;
             const int j = lane & 3;
             const float bj = j < VAL_CH ? P.val_b[j] : 0.0f;
-            // three independent accumulation chains, one per kernel row (dy = -1, 0, +1), summed at the end in a
-            // fixed order: dependent 4x4x1 MFMAs issue only every ~4 passes, independent ones back to back
-            f32x4 ar[3] = {{bj, bj, bj, bj}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            // NINE independent accumulation chains, one per tap, summed at the end in a fixed order (the three taps of a kernel
+            // row first, then the rows): a dependent 4x4x1 MFMA issues only every ~4 passes, and with three chains (one per
+            // kernel row) the value conv still took 9.6 us of a three-board workgroup's 139 (tools/variant_trace.py)
+            f32x4 ar[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) ar[t] = (f32x4){0, 0, 0, 0};
+            ar[0] = (f32x4){bj, bj, bj, bj};
             const float *xr[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -1130,32 +1134,29 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
                 xr[t] = act + (ok ? (r + (t / 3 - 1) * COLS + (t % 3 - 1)) * STRIDE : ZERO_IDX);
             }
             const float *wt = P.val_w4 + j * 4;                                // [tap][c / 4][j][c % 4]
-            for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll 2
-                for (int c = 0; c < CP; c += 4) {
-                    float4 w[3];
-                    const float *a[3];
+            for (int c = 0; c < CP; c += 4) {
+                float4 w[9], x[9];             // rows are 16-byte aligned: four input channels per LDS read
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        w[dy] = *reinterpret_cast<const float4 *>(wt + ((size_t)(dy * 3 + dx) * CP + c) * 4);
-                        a[dy] = dx == 0 ? xr[dy * 3] : (dx == 1 ? xr[dy * 3 + 1] : xr[dy * 3 + 2]);
-                    }
-                    float4 x[3];               // rows are 16-byte aligned: four input channels per LDS read
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) x[dy] = *reinterpret_cast<const float4 *>(a[dy] + c);
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) ar[dy] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[dy].x, w[dy].x, ar[dy], 0, 0, 0);
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) ar[dy] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[dy].y, w[dy].y, ar[dy], 0, 0, 0);
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) ar[dy] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[dy].z, w[dy].z, ar[dy], 0, 0, 0);
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) ar[dy] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[dy].w, w[dy].w, ar[dy], 0, 0, 0);
+                for (int t = 0; t < 9; ++t) {
+                    w[t] = *reinterpret_cast<const float4 *>(wt + ((size_t)t * CP + c) * 4);
+                    x[t] = *reinterpret_cast<const float4 *>(xr[t] + c);
                 }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) ar[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[t].x, w[t].x, ar[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) ar[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[t].y, w[t].y, ar[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) ar[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[t].z, w[t].z, ar[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) ar[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[t].w, w[t].w, ar[t], 0, 0, 0);
             }
             f32x4 av;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = (ar[0][i] + ar[1][i]) + ar[2][i];
+            for (int i = 0; i < 4; ++i) {
+                const float r0 = (ar[0][i] + ar[1][i]) + ar[2][i], r1 = (ar[3][i] + ar[4][i]) + ar[5][i], r2 = (ar[6][i] + ar[7][i]) + ar[8][i];
+                av[i] = (r0 + r1) + r2;
+            }
             const int rb = wv * 64 + (lane & ~3);
 #pragma unroll
             for (int i = 0; i < 4; ++i) hval[(rb + i) * 4 + j] = fmaxf(av[i], 0.0f);   // hval is not read before the barriers below
