@@ -3,7 +3,7 @@
 namespace azsp {
 void fwd_c4_32_small(const FwdArgs &a) { launch_forward<Connect4, 1, 1, 1>(a); }
 void fwd_c4_32_big(const FwdArgs &a) { launch_forward<Connect4, 1, 2, 0>(a); }
-void fwd_c4_64_one(const FwdArgs &a) { launch_forward<Connect4, 2, 1, 2, 2, 2>(a); }       // (PF = 2: the tower on three 16-row tiles)
+void fwd_c4_64_one(const FwdArgs &a) { launch_forward<Connect4, 2, 1, 2, 2, 2, true>(a); }       // (PF = 2: the tower on three 16-row tiles)
 void fwd_c4_64_mid(const FwdArgs &a) { launch_forward<Connect4, 2, 2, 3, 2, 2, true>(a); }       // (PF = 3: eight 16-row tiles, static tap skipping)
 void fwd_c4_96(const FwdArgs &a) { launch_forward<Connect4, 3, 1, 1>(a); }
 void fwd_c4_128_one(const FwdArgs &a) { launch_forward<Connect4, 4, 1, 2, 4, 2>(a); }

@@ -592,60 +592,68 @@ __device__ __forceinline__ void conv_tile16c(f32x4m (&acc)[NRT], const float *ac
 // inner cells of the top rows + a top-left corner, 3 = the same at the bottom, 4..7 = interior cells, the two right-column
 // cells left over and two padding rows (build_row_order's third table).  60 of 72 tile-taps remain (the six-board kernels'
 // 5/6).  Which tile-taps exist is static, so a layer is ONE straight-line sequence of 60 x SPT steps (tile-tap x 16-channel
-// group, four v_mfma_f32_16x16x4_f32 each) as in tower_layer: step i issues the 16-byte activation read of step i + 2 (four
-// rotating buffers) and its own MFMAs; a tap's last tile reloads each weight quad for the next tap right after using it.
+// group, four v_mfma_f32_16x16x4_f32 each; t16_layer) as in tower_layer: step i issues the 16-byte activation read of step i + 2 (four
+// rotating buffers) and its own MFMAs; a tap's first tile loads the NEXT tap's weight quads into the other of two buffers.
 // Same slot order and weights as conv_tile16c; same bits as every other variant.
-struct T16Step { int tap, tile, q, last; };
+struct T16Step { int tap, tile, q, first, last; };
 __host__ __device__ constexpr bool t16m_needs(int tile, int tap) {
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
     return tile == 0 ? dx != -1 : (tile == 1 ? dx != 1 : (tile == 2 ? dy != -1 : (tile == 3 ? dy != 1 : true)));
 }
-template <int SPT>
-struct T16MSched {
-    static constexpr int NSTEP = 60 * SPT;
+// NRT row tiles; SK: the three-board tile classes above (else every tile takes every tap: the one-board kernel's three tiles)
+template <int NRT, bool SK, int SPT>
+struct T16Sched {
+    static constexpr int NSTEP = (SK ? 60 : 9 * NRT) * SPT;
     T16Step s[NSTEP + 2];
-    constexpr T16MSched() : s{} {
+    constexpr T16Sched() : s{} {
         int n = 0;
         for (int tap = 0; tap < 9; ++tap) {
-            int last_tile = 0;
-            for (int tile = 0; tile < 8; ++tile) if (t16m_needs(tile, tap)) last_tile = tile;
-            for (int tile = 0; tile < 8; ++tile) {
-                if (!t16m_needs(tile, tap)) continue;
-                for (int q = 0; q < SPT; ++q) { s[n].tap = tap; s[n].tile = tile; s[n].q = q; s[n].last = tile == last_tile; ++n; }
+            int first_tile = -1, last_tile = -1;
+            for (int tile = NRT - 1; tile >= 0; --tile) if (!SK || t16m_needs(tile, tap)) { first_tile = tile; if (last_tile < 0) last_tile = tile; }
+            for (int tile = 0; tile < NRT; ++tile) {
+                if (SK && !t16m_needs(tile, tap)) continue;
+                for (int q = 0; q < SPT; ++q) { s[n].tap = tap; s[n].tile = tile; s[n].q = q; s[n].first = tile == first_tile; s[n].last = tile == last_tile; ++n; }
             }
         }
         s[n] = s[n - 1]; s[n + 1] = s[n - 1];          // the reads past the end repeat the last one
     }
 };
-template <int SPT>
-struct T16MHolder { static constexpr T16MSched<SPT> SC{}; };
+template <int NRT, bool SK, int SPT>
+struct T16Holder { static constexpr T16Sched<NRT, SK, SPT> SC{}; };
 
-template <class G, int SPT, int NT, int STRIDE, int I>
-__device__ __forceinline__ void t16m_step(f32x4m (&acc)[8], const float *act, const int (&rix)[8], const uint32_t (&vmk)[8], int zero_idx,
-                                          const float *wq, float4 (&wb)[SPT], float4 (&xa)[4], int &rbase) {
-    constexpr T16Step st = T16MHolder<SPT>::SC.s[I], nx = T16MHolder<SPT>::SC.s[I + 2];
+template <class G, int NRT, bool SK, int SPT, int NT, int STRIDE, int I>
+__device__ __forceinline__ void t16_step(f32x4m (&acc)[NRT], const float *act, const int (&rix)[NRT], const uint32_t (&vmk)[NRT], int zero_idx,
+                                         const float *wq, float4 (&wb)[2][SPT], float4 (&xa)[4], int &rbase) {
+    constexpr T16Step st = T16Holder<NRT, SK, SPT>::SC.s[I], nx = T16Holder<NRT, SK, SPT>::SC.s[I + 2];
+    constexpr bool DB = SPT <= 4;                                     // 64 channels: two weight buffers, taps alternate (at 128 the second costs more than it hides)
+    constexpr int cur = DB ? (st.tap & 1) : 0;
     constexpr size_t QSTR = (size_t)2 * NT * 64 * 4;                  // floats between consecutive 16-channel input groups
-    if constexpr (nx.q == 0 && I + 2 < T16MSched<SPT>::NSTEP)         // step i + 2 opens a new (tile, tap) block
+    if constexpr (nx.q == 0 && I + 2 < T16Sched<NRT, SK, SPT>::NSTEP) // step i + 2 opens a new (tile, tap) block
         rbase = tower_aindex<G, STRIDE>(rix[nx.tile], vmk[nx.tile], nx.tap, zero_idx);
     xa[(I + 2) % 4] = *reinterpret_cast<const float4 *>(act + rbase + 16 * nx.q);
+    if constexpr (DB && st.first != 0)                                // the NEXT tap's (past the layer's end: the next layer's) group q, a whole
+        wb[cur ^ 1][st.q] = *reinterpret_cast<const float4 *>(wq + (size_t)((st.tap + 1) * SPT + st.q) * QSTR);      // tap of MFMAs ahead of its use
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[st.tile] = conv_mma16(f4c(xa[I % 4], k), f4c(wb[st.q], k), acc[st.tile]);
-    if constexpr (st.last != 0)                                       // the next tap's (past the layer's end: the next layer's) group q
-        wb[st.q] = *reinterpret_cast<const float4 *>(wq + (size_t)((st.tap + 1) * SPT + st.q) * QSTR);
+    for (int k = 0; k < 4; ++k) acc[st.tile] = conv_mma16(f4c(xa[I % 4], k), f4c(wb[cur][st.q], k), acc[st.tile]);
+    if constexpr (!DB && st.last != 0)                                // one buffer: the tap's last tile reloads each quad right after using it
+        wb[0][st.q] = *reinterpret_cast<const float4 *>(wq + (size_t)((st.tap + 1) * SPT + st.q) * QSTR);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (I + 1 < T16MSched<SPT>::NSTEP) t16m_step<G, SPT, NT, STRIDE, I + 1>(acc, act, rix, vmk, zero_idx, wq, wb, xa, rbase);
+    if constexpr (I + 1 < T16Sched<NRT, SK, SPT>::NSTEP) t16_step<G, NRT, SK, SPT, NT, STRIDE, I + 1>(acc, act, rix, vmk, zero_idx, wq, wb, xa, rbase);
 }
-template <class G, int SPT, int NT, int STRIDE>
-__device__ __forceinline__ void t16m_layer(f32x4m (&acc)[8], const float *act, const int (&rix)[8], const uint32_t (&vmk)[8], int zero_idx,
-                                           const float *wq, float4 (&wb)[SPT]) {
-    constexpr T16Step s0 = T16MHolder<SPT>::SC.s[0], s1 = T16MHolder<SPT>::SC.s[1];
+template <class G, int NRT, bool SK, int SPT, int NT, int STRIDE>
+__device__ __forceinline__ void t16_layer(f32x4m (&acc)[NRT], const float *act, const int (&rix)[NRT], const uint32_t (&vmk)[NRT], int zero_idx,
+                                          const float *wq, float4 (&wb)[2][SPT]) {
+    constexpr T16Step s0 = T16Holder<NRT, SK, SPT>::SC.s[0], s1 = T16Holder<NRT, SK, SPT>::SC.s[1];
     float4 xa[4];
     int rbase = tower_aindex<G, STRIDE>(rix[s0.tile], vmk[s0.tile], s0.tap, zero_idx);
     xa[0] = *reinterpret_cast<const float4 *>(act + rbase + 16 * s0.q);
     if constexpr (s1.q == 0) rbase = tower_aindex<G, STRIDE>(rix[s1.tile], vmk[s1.tile], s1.tap, zero_idx);
     xa[1] = *reinterpret_cast<const float4 *>(act + rbase + 16 * s1.q);
     __builtin_amdgcn_sched_barrier(0);
-    t16m_step<G, SPT, NT, STRIDE, 0>(acc, act, rix, vmk, zero_idx, wq, wb, xa, rbase);
+    t16_step<G, NRT, SK, SPT, NT, STRIDE, 0>(acc, act, rix, vmk, zero_idx, wq, wb, xa, rbase);
+    if constexpr (SPT <= 4)
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) wb[0][q] = wb[1][q];            // tap 8 used buffer 0 and filled buffer 1 with the next layer's tap 0
 }
 
 // (C/D layout of v_mfma_f32_32x32x2_f32: register v of lane l holds row (v & 3) + 8 * (v >> 2) + 4 * (l >> 5), column
@@ -913,11 +921,11 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
                     xr16[t] = (f32x4m){x.x + bq.x, x.y + bq.y, x.z + bq.z, x.w + bq.w};
                 }
             }
-            constexpr int NWB = TILE16C ? QC16 : SPT16;       // weight quads in registers: a chunk (one board) or a whole tap (three)
-            float4 wbc[NWB];
+            constexpr int NWB = SPT16;                        // weight quads in registers: a whole tap
+            float4 wbc[2][NWB];
             const float *wq0 = P.conv_w16 + ((size_t)(tid >> 6) * 64 + lane) * 4;
 #pragma unroll
-            for (int j = 0; j < NWB; ++j) wbc[j] = *reinterpret_cast<const float4 *>(wq0 + (size_t)j * 2 * NT * 64 * 4);
+            for (int j = 0; j < NWB; ++j) wbc[0][j] = *reinterpret_cast<const float4 *>(wq0 + (size_t)j * 2 * NT * 64 * 4);
             for (int layer = 0; layer < nl; ++layer) {
                 const bool second = layer & 1;
                 const float *blc = P.conv_b16 + (size_t)layer * P.conv_b_stride + c16;
@@ -930,8 +938,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
 #pragma unroll
                     for (int t = 0; t < NRT; ++t) a16[t] = (f32x4m){bq.x, bq.y, bq.z, bq.w};
                 }
-                if constexpr (TILE16C) conv_tile16c<G, 3, SPT16, NT, STRIDE>(a16, act, rix, vmk, ZERO_IDX + 4 * kq, wq0 + (size_t)layer * P.conv_w_stride, wbc);
-                else t16m_layer<G, SPT16, NT, STRIDE>(a16, act, rix, vmk, ZERO_IDX + 4 * kq, wq0 + (size_t)layer * P.conv_w_stride, wbc);
+                t16_layer<G, NRT, TILE16M, SPT16, NT, STRIDE>(a16, act, rix, vmk, ZERO_IDX + 4 * kq, wq0 + (size_t)layer * P.conv_w_stride, wbc);
                 if (layer < 16) STAMP(3 + 3 * layer);
                 float4 b2q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (fold) b2q = *reinterpret_cast<const float4 *>(blc + 2 * (size_t)P.conv_b_stride + 4 * kq);
