@@ -235,7 +235,7 @@ int resnet_load(ResNetDev *n, const float *blob, size_t n_floats, hipStream_t s)
         }
         for (int o = 0; o < g.C; ++o) host[n->o_conv_b + (size_t)l * n->conv_b_stride + o] = b[o];
         if (n->has_w16) {
-            // conv_tile16c: [tap][16-channel input group][16-channel output tile][lane][4]; lane = (A row m = output SLOT of the
+            // t16_layer: [tap][16-channel input group][16-channel output tile][lane][4]; lane = (A row m = output SLOT of the
             // tile) + 16 * quarter; element j = input channel 16 * group + t16_chan(quarter, j); slot m = channel t16_chan(m >> 2, m & 3)
             float *dst = host.data() + n->o_conv_w16 + (size_t)l * n->conv_w_stride;
             const int G16 = g.Cp / 16;

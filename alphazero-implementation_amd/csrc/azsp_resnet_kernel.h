@@ -544,48 +544,10 @@ __device__ __forceinline__ void conv_tile16(f32x4m (&acc)[5][2], float (&vacc)[2
 // (one 16-byte store).  One pass converts the stem's output to slot order, one converts the tower's output back.
 __host__ __device__ constexpr int t16_chan(int q, int j) { return 4 * (q & 1) + (q >> 1) + 2 * (j & 1) + 8 * (j >> 1); }
 
-// A wave owns ONE 16-channel output tile x NRT row tiles.  Same rolled software pipeline as conv_tile16.
-template <class G, int NRT, int SPT, int NT, int STRIDE>
-__device__ __forceinline__ void conv_tile16c(f32x4m (&acc)[NRT], const float *act, const int (&ridx)[NRT], const uint32_t (&vmask)[NRT],
-                                             int zero_idx, const float *wq, float4 (&wb)[Tile16Geo<SPT>::QC]) {
-    constexpr int QC = Tile16Geo<SPT>::QC, CPT = SPT / QC, NCHUNK = 9 * CPT, BODY = NRT * QC;
-    constexpr size_t QSTR = (size_t)2 * NT * 64 * 4;                  // floats between consecutive 16-channel input groups
-    static_assert(SPT % QC == 0 && BODY % 4 == 0 && QC >= 2, "chunking");
-    float4 xa[4];
-    int base[NRT];
-#pragma unroll
-    for (int t = 0; t < NRT; ++t) base[t] = tower_aindex<G, STRIDE>(ridx[t], vmask[t], 0, zero_idx);
-    xa[0] = *reinterpret_cast<const float4 *>(act + base[0]);
-    xa[1] = *reinterpret_cast<const float4 *>(act + base[0] + 16);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-    for (int c = 0; c < NCHUNK; ++c) {
-        const int cn = c + 1 < NCHUNK ? c + 1 : c;
-        const int tapn = cn / CPT, q0n = (cn % CPT) * QC;
-        const int nbase0 = tower_aindex<G, STRIDE>(ridx[0], vmask[0], tapn, zero_idx) + 16 * q0n;
-        const int q0 = (c % CPT) * QC;
-        const float *wnext = wq + (size_t)(c * QC + QC) * QSTR;       // group 0 of the next chunk
-#pragma unroll
-        for (int i = 0; i < BODY; ++i) {
-            const int t = i / QC, q = i % QC;
-            const int j = i + 2;                                      // the step whose activations are requested now
-            if (j < BODY) xa[j % 4] = *reinterpret_cast<const float4 *>(act + base[j / QC] + 16 * (q0 + j % QC));
-            else xa[j % 4] = *reinterpret_cast<const float4 *>(act + nbase0 + 16 * (j - BODY));
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[t] = conv_mma16(f4c(xa[i % 4], k), f4c(wb[q], k), acc[t]);
-            if (t == NRT - 1) wb[q] = *reinterpret_cast<const float4 *>(wnext + (size_t)q * QSTR);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (cn != c && cn % CPT == 0) {                               // the next chunk opens a new tap
-#pragma unroll
-            for (int t = 0; t < NRT; ++t) base[t] = tower_aindex<G, STRIDE>(ridx[t], vmask[t], tapn, zero_idx);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// 16-row tiles for THREE Connect-4 boards per workgroup, with static tap skipping (mid-size batches, and the workhorse of the
-// evaluation cache, whose launches hold a few hundred positions)
+// The static schedule of the Connect-4 16-row-tile kernels: ONE board per workgroup (three tiles, every tap), and THREE
+// boards per workgroup with static tap skipping (mid-size batches, and the workhorse of the evaluation cache, whose
+// launches hold a few hundred positions)
 // ------------------------------------------------------------------------------------------------
 // In 32-row tiles the 126 cells of three boards cannot skip taps (no class of cells that lack the same taps fills a tile);
 // in 16-row tiles they can: tile 0 = 16 left-column cells (lack dx = -1: 3 of 9 taps), 1 = 16 right-column cells, 2 = the 15
@@ -593,8 +555,9 @@ __device__ __forceinline__ void conv_tile16c(f32x4m (&acc)[NRT], const float *ac
 // cells left over and two padding rows (build_row_order's third table).  60 of 72 tile-taps remain (the six-board kernels'
 // 5/6).  Which tile-taps exist is static, so a layer is ONE straight-line sequence of 60 x SPT steps (tile-tap x 16-channel
 // group, four v_mfma_f32_16x16x4_f32 each; t16_layer) as in tower_layer: step i issues the 16-byte activation read of step i + 2 (four
-// rotating buffers) and its own MFMAs; a tap's first tile loads the NEXT tap's weight quads into the other of two buffers.
-// Same slot order and weights as conv_tile16c; same bits as every other variant.
+// rotating buffers) and its own MFMAs; at 64 channels a tap's first tile loads the NEXT tap's weight quads into the other of
+// two buffers, at 128 the tap's last tile reloads each quad of the one buffer after its last use.  The one-board kernel
+// runs the same sequence over its three tiles without skipping (SK = false).  Same bits as every other variant.
 struct T16Step { int tap, tile, q, first, last; };
 __host__ __device__ constexpr bool t16m_needs(int tile, int tap) {
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -680,7 +643,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     // every other wave grid with one column tile per wave: the rolled form of the same software pipeline (conv_rolled)
     // one 9x9 board per workgroup from 96 channels on: the tower on five 16-row tiles + the corner cell (conv_tile16)
     constexpr bool TILE16 = std::is_same<G, Gomoku9>::value && PF == 0 && CW == NT && RW == 1 && MT == 3 && NT >= 3;
-    // one Connect-4 board per workgroup on three 16-row tiles (conv_tile16c): PF == 2 marks these instantiations; every
+    // one Connect-4 board per workgroup on three 16-row tiles (t16_layer, SK = false): PF == 2 marks these instantiations; every
     // wave owns one 16-channel output tile
     constexpr bool TILE16C = std::is_same<G, Connect4>::value && PF == 2;
     static_assert(!TILE16C || (MT == 1 && WG_ROWS / CELLS == 1 && RW * CW * 16 == 32 * NT), "one board, one 16-channel tile per wave");
@@ -877,7 +840,7 @@ __global__ __launch_bounds__(64 * RW * CW, (RW * CW == 4 && CW == 1 && MT == 1 &
     }
     if constexpr (TILE16C || TILE16M) {
         // ---- the whole tower on 16-row tiles, activations in slot order: ONE board = three tiles (cells 0..47, 42 real;
-        //      conv_tile16c) or THREE boards = eight tiles in the tap-skipping order of P.perm (t16m_layer) ----
+        //      t16_layer) or THREE boards = eight tiles in the tap-skipping order of P.perm (t16m_layer) ----
         constexpr int NRT = TILE16C ? 3 : 8, TROWS = 16 * NRT;
         constexpr int CP16 = CP / 4, ITEMS = TROWS * CP16, PER = (ITEMS + NTHREADS - 1) / NTHREADS;
         const int nl = 2 * P.blocks;
