@@ -16,7 +16,8 @@ for b in pb:
     for c in range(7):
         h = rng.randint(0, 6)
         b[6 - h:, c] = rng.choice([-1, 1], size=h)
-with Engine("connect4", B, 1, res_blocks=4, channels=64) as e:
+F16 = len(sys.argv) > 3 and sys.argv[3] == "f16"        # phase trace of the split-fp16 kernel (six-board form)
+with Engine("connect4", B, 1, res_blocks=4, channels=64, f16_split=F16) as e:
     e.load_resnet(blob)
     for _ in range(1500):
         e.predict(pb)
