@@ -428,6 +428,9 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     // 64 channels on the 2 x 2 wave grid: the statically scheduled tower (nine taps per layer, so the two weight
     // buffers swap roles from layer to layer: the layer's parity is a template parameter)
     constexpr bool STATIC16 = (ABL & 7) == 0 && NR == 256 && WR == 2 && (CT == 2 || CT == 4);
+    // above 128 channels a tap's weights for one column tile (SL x 8 registers) no longer fit beside the accumulators and the
+    // residual: those nets stream them two slabs ahead (conv16: same order of sums per output -- taps, then slabs, ascending)
+    constexpr bool WIDE = CT > 4;
     h8 wh[3][2], wl[3][2];
     if constexpr (STATIC16) {
 #pragma unroll
@@ -450,7 +453,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
             const int zb = ZERO_BYTE + half * 16;
             if (wr == 0) tower16_layer<G, 0, SL, CT, ROW_BYTES, PLANE_BYTES>(acc, smem16, abyte, vmask, zb, wq, wh, wl);
             else tower16_layer<G, 1, SL, CT, ROW_BYTES, PLANE_BYTES>(acc, smem16, abyte, vmask, zb, wq, wh, wl);
-        } else if constexpr ((ABL & 7) == 0)
+        } else if constexpr ((ABL & 7) == 0 && !WIDE)
             conv16s<G, MT, 9, SL, CT>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
                                       abyte, vmask, need, ROW_BYTES, ZERO_BYTE + half * 16, lane);
         else
@@ -485,9 +488,11 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
             accv[i] = bv;
         }
     }
-    conv16s<G, PT, 1, SL, 1>(accp, P.pol_w, plane_hi, PLANE_BYTES, hbyte, hmask, hneed, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+    if constexpr (WIDE) conv16<G, PT, 1, SL, 1>(accp, P.pol_w, plane_hi, PLANE_BYTES, hbyte, hmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+    else conv16s<G, PT, 1, SL, 1>(accp, P.pol_w, plane_hi, PLANE_BYTES, hbyte, hmask, hneed, ROW_BYTES, ZERO_BYTE + half * 16, lane);
     STAMP16(51);
-    conv16s<G, PT, 9, SL, 1>(accv, P.val_w, plane_hi, PLANE_BYTES, hbyte, hmask, hneed, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+    if constexpr (WIDE) conv16<G, PT, 9, SL, 1>(accv, P.val_w, plane_hi, PLANE_BYTES, hbyte, hmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+    else conv16s<G, PT, 9, SL, 1>(accv, P.val_w, plane_hi, PLANE_BYTES, hbyte, hmask, hneed, ROW_BYTES, ZERO_BYTE + half * 16, lane);
     STAMP16(52);
     __syncthreads();
 #pragma unroll
@@ -623,7 +628,7 @@ static void build_row_order16(int WR, int32_t *perm) {
 ResNet16Dev *resnet16_create(int game, int blocks, int channels) {
     if (game != 0 || blocks < 0 || channels <= 0) return nullptr;
     const int CT = (channels + 31) / 32;
-    if (CT < 1 || CT > 4) return nullptr;
+    if (CT < 1 || CT > 8) return nullptr;      // up to 256 channels (two fp16 planes of 128 rows x 264 halves: 136 KB of LDS)
     ResNet16Dev *n = new ResNet16Dev();
     n->CT = CT; n->C = channels; n->blocks = blocks; n->cells = Connect4::CELLS; n->A = Connect4::A;
     const int SL = 2 * CT, CP = 32 * CT;
@@ -823,6 +828,21 @@ static void forward_sized(Net16Params &P, const Fwd16 &a, bool by_count, hipEven
     if (big) go16<CT, 2, 256>(P, a, g_mid, 0, (one || mid) ? nullptr : e0, e1);
 }
 
+// 160 .. 256 channels: the planes of 256 rows do not fit in LDS; ONE board per workgroup (64 rows) up to 256 boards, three
+// (128 rows) beyond; one row group of CT waves (a second would read every weight twice).
+template <int CT>
+static void forward_wide(Net16Params &P, const Fwd16 &a, bool by_count, hipEvent_t e0, hipEvent_t e1) {
+    constexpr int g_one = 256;
+    if (!by_count) {
+        if (a.max_leaves <= g_one) go16<CT, 1, 64>(P, a, 0, 0, e0, e1);
+        else go16<CT, 1, 128>(P, a, 0, 0, e0, e1);
+        return;
+    }
+    const bool mid = a.max_leaves > g_one;
+    go16<CT, 1, 64>(P, a, 0, mid ? g_one : 0, e0, mid ? nullptr : e1);
+    if (mid) go16<CT, 1, 128>(P, a, g_one, 0, nullptr, e1);
+}
+
 void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32_t *leaf_slot, const int32_t *n_leaf,
                       int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, bool by_count,
                       double *flop_acc, double wg_flops, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -885,6 +905,10 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
             break;
         }
         case 3: go16<3, 2>(P, a, 0, 0, ev_start, ev_stop); break;
+        case 5: forward_wide<5>(P, a, by_count, ev_start, ev_stop); break;
+        case 6: forward_wide<6>(P, a, by_count, ev_start, ev_stop); break;
+        case 7: forward_wide<7>(P, a, by_count, ev_start, ev_stop); break;
+        case 8: forward_wide<8>(P, a, by_count, ev_start, ev_stop); break;
         default:
             if (wr_env == 4) go16<4, 4>(P, a, 0, 0, ev_start, ev_stop);
             else if (wr_env == 2) go16<4, 2>(P, a, 0, 0, ev_start, ev_stop);

@@ -253,8 +253,6 @@ def test_resnet_model_predict_uses_device_kernel(azsp, blocks, ch, f16, monkeypa
     channel-tile count the kernel is instantiated for (C padded to 32/64/128).  Tolerance NET_TOL for the BASELINE
     geometries, NET_TOL_WIDE otherwise; also printed: both against a float64 forward."""
     import torch
-    if f16 and ch > 128:
-        pytest.skip("the split-fp16 kernel covers up to 128 channels")
     monkeypatch.setenv("AZSP_F16_SPLIT", "1" if f16 else "0")
     torch.manual_seed(blocks * 1000 + ch)
     net = azsp.ResNet((6, 7), 7, blocks, ch)
