@@ -223,7 +223,7 @@ void resnet16_destroy(ResNet16Dev *);
 int resnet16_load(ResNet16Dev *, const float *blob, size_t n_floats, hipStream_t s);
 void resnet16_forward(ResNet16Dev *, const u64 *leaf0, int board_stride, const int32_t *leaf_slot, const int32_t *n_leaf,
                       int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, bool by_count = false,
-                      double *flop_acc = nullptr, double wg_flops = 0.0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-double resnet16_wg_flops(const ResNet16Dev *, double flops_per_board);      // fp16 MFMA FLOP one 6-board workgroup executes
+                      double *flop_acc = nullptr, double flops_per_board = 0.0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+double resnet16_exec_flops_per_board(const ResNet16Dev *, double flops_per_board, int max_leaves);      // executed fp16 MFMA FLOP per board of the form a launch of that capacity takes
 
 }  // namespace azsp

@@ -413,7 +413,7 @@ static double variant_wg_flops(const ResNetDev *n, const Variant *v, int *boards
 }
 double resnet_exec_flops_per_board(const ResNetDev *n, int game, int max_leaves) {
     if (!n) return 0.0;
-    if (n->f16) return resnet16_wg_flops(n->f16, n->flops_per_board) / 6.0;
+    if (n->f16) return resnet16_exec_flops_per_board(n->f16, n->flops_per_board, max_leaves);
     const Variant *v = pick_variant(n, game, max_leaves);
     if (!v) return 0.0;
     int tb = 1;
@@ -486,7 +486,7 @@ static void forward_impl(ResNetDev *n, int game, const u64 *leaf0, int board_str
                          bool by_count, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n->f16) {
         resnet16_forward(n->f16, leaf0, board_stride, leaf_slot, n_leaf, max_leaves, out_p, p_stride, out_v, v_stride, s, by_count,
-                         n->d_flop_acc, resnet16_wg_flops(n->f16, n->flops_per_board), ev_start, ev_stop);
+                         n->d_flop_acc, n->flops_per_board, ev_start, ev_stop);
         return;
     }
     const Variant *v = pick_variant(n, game, max_leaves);

@@ -52,14 +52,15 @@ struct Net16Params {
     const int32_t *perm;               // [256] GEMM row -> board-cell row for this wave grid (tap skipping)
     unsigned long long *dbg;           // phase timestamps of the ABL = 8 diagnostic instantiation, else nullptr
     double *flop_acc;                  // device accumulator of executed matrix-pipe FLOP, or nullptr
-    double wg_flops;                   // fp16 MFMA FLOP one workgroup executes (resnet16_wg_flops)
+    double wg_flops;                   // fp16 MFMA FLOP one workgroup executes (set per launch from the two figures below)
+    double tower_row_flops, rest_board_flops;   // executed fp16 FLOP of the tower per GEMM row (no tap skipped), of stem + heads per board
     int gate;                          // launch gate as in the fp32 kernel: (lo / 16) | (hi / 16) << 16, 0 = none
 };
 // phase timestamp (100 MHz clock) of wave 0 of each workgroup; compiled only into the ABL & 8 diagnostic build
 #define STAMP16(k) do { if constexpr ((ABL & 8) != 0) { if (tid == 0) P.dbg[(size_t)blockIdx.x * 64 + (k)] = wall_clock64(); } } while (0)
 
 struct ResNet16Dev {
-    int CT = 0, C = 0, blocks = 0, cells = 0, A = 0;
+    int game = 0, CT = 0, C = 0, blocks = 0, cells = 0, A = 0, AS = 8;      // AS: floats per (channel, cell) row of the policy FC weights
     unsigned char *d_blob = nullptr;
     size_t bytes = 0;
     size_t o_stem_w, o_conv_w, o_pol_w, o_val_w;                                    // byte offsets of h8 arrays
@@ -138,6 +139,73 @@ __device__ __forceinline__ void conv16(f32x16 (&acc)[NTILE], const h8 *__restric
                                                           : arow_n[0];
                 ah_n = *reinterpret_cast<const h8 *>(nx);
                 al_n = *reinterpret_cast<const h8 *>(nx + plane_bytes);
+                acc[i] = mfma16(ah, bh, acc[i]);
+                acc[i] = mfma16(ah, bl, acc[i]);
+                acc[i] = mfma16(al, bh, acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i) arow[i] = arow_n[i];
+    }
+}
+
+// conv16 with deeper rings, for the one-row-group forms with two or three row tiles per wave (the wide nets' one-board forms,
+// Gomoku): 9-12 MFMAs per slab do not cover an L2 / MALL round trip of the weights two slabs ahead, nor three MFMAs an LDS
+// read under eight waves' traffic.  Same order of sums.  (With four row tiles per wave the rotating form above is faster:
+// 3072 boards at 4 x 192 2.10 against 2.49 ms.)
+template <class G, int NTILE, int TAPS, int SL, int CT, int PD>
+__device__ __forceinline__ void conv16r(f32x16 (&acc)[NTILE], const h8 *__restrict__ w, const unsigned char *plane_hi,
+                                       int plane_bytes, const int (&abyte)[NTILE], const uint32_t (&vmask)[NTILE],
+                                       int row_bytes, int zero_byte, int lane) {
+    // Written as a software pipeline over the flattened (tap, slab, row tile) sequence: the A fragments of the next tile
+    // and the B fragments (weights) PD slabs ahead are requested before the three MFMAs of the current tile; the weights
+    // sit in a ring of PD register pairs indexed statically (PD divides SL).  PD = 2 is enough where the six-board form's
+    // eight row tiles give a slab 24 MFMAs; the one-row-group forms of the wide nets have 9-12 MFMAs per slab and need the
+    // weights of an L2 / MALL round trip in flight: PD = 4.  hipcc's scheduler re-orders this freely (measured: same speed
+    // as the naive loop; pinning the order with sched_barrier makes its waits conservative: -6 % at 4096 boards, +13 % at
+    // 100) -- see DESIGN.md section 10.
+    static_assert(SL % PD == 0 || TAPS * SL < PD, "static ring indices");
+    auto arow_of = [&](int tap, int i) -> const unsigned char * {
+        const int t9 = (TAPS == 9) ? tap : 4;
+        const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+        return plane_hi + (((vmask[i] >> t9) & 1u) ? abyte[i] + (dy * G::COLS + dx) * row_bytes : zero_byte);
+    };
+    auto wptr = [&](int q) -> const h8 * {          // q = tap * SL + slab (clamped at the end of the layer)
+        const int qq = q < TAPS * SL ? q : TAPS * SL - 1;
+        return w + ((size_t)qq * CT) * 2 * 64 + lane;
+    };
+    // A fragments: a ring of AR register pairs, the pair of step j + AD requested at step j (a step = one row tile of one slab)
+    constexpr int STEPS = SL * NTILE, AR = STEPS % 4 == 0 ? 4 : 2, AD = AR / 2;
+    const unsigned char *arow[NTILE], *arow_n[NTILE];
+#pragma unroll
+    for (int i = 0; i < NTILE; ++i) arow[i] = arow_of(0, i);
+    h8 xh[AR], xl[AR];
+#pragma unroll
+    for (int j = 0; j < AD; ++j) {
+        const unsigned char *a0 = arow[j % NTILE] + (j / NTILE) * 32;
+        xh[j] = *reinterpret_cast<const h8 *>(a0);
+        xl[j] = *reinterpret_cast<const h8 *>(a0 + plane_bytes);
+    }
+    h8 rh[PD], rl[PD];                              // slabs q .. q + PD - 1
+#pragma unroll
+    for (int k = 0; k < PD; ++k) { rh[k] = wptr(k)[0]; rl[k] = wptr(k)[64]; }
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const int tn = tap + 1 < TAPS ? tap + 1 : tap;
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i) arow_n[i] = arow_of(tn, i);
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) {
+            const h8 bh = rh[sl % PD], bl = rl[sl % PD];
+            const h8 *wn = wptr(tap * SL + sl + PD);
+            rh[sl % PD] = wn[0]; rl[sl % PD] = wn[64];
+#pragma unroll
+            for (int i = 0; i < NTILE; ++i) {
+                const int j = sl * NTILE + i, jn = j + AD;                 // (static after unrolling)
+                const unsigned char *nx = jn < STEPS ? arow[jn % NTILE] + (jn / NTILE) * 32
+                                                     : arow_n[(jn - STEPS) % NTILE] + ((jn - STEPS) / NTILE) * 32;
+                const h8 ah = xh[j % AR], al = xl[j % AR];
+                xh[jn % AR] = *reinterpret_cast<const h8 *>(nx);
+                xl[jn % AR] = *reinterpret_cast<const h8 *>(nx + plane_bytes);
                 acc[i] = mfma16(ah, bh, acc[i]);
                 acc[i] = mfma16(ah, bl, acc[i]);
                 acc[i] = mfma16(al, bh, acc[i]);
@@ -310,8 +378,9 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     _Float16 *act_hi = reinterpret_cast<_Float16 *>(smem16);
     _Float16 *act_lo = reinterpret_cast<_Float16 *>(smem16 + PLANE_BYTES);
     float *hb = reinterpret_cast<float *>(smem16);               // after the tower: [256][HB_STRIDE] head activations
-    float *part = hb + F16_ROWS * HB_STRIDE;                     // [256][8], then [TB][8] logits
-    constexpr int HEAD_BYTES = (F16_ROWS * HB_STRIDE + F16_ROWS * 8 + TB * 8) * 4;
+    float *part = hb + F16_ROWS * HB_STRIDE;                     // [256][8], then the logits: [TB][8], or [TB][AP] + [TB] value logits
+    constexpr int LOGIT_FLOATS = A <= 7 ? TB * 8 : TB * (G::AP + 8);
+    constexpr int HEAD_BYTES = (F16_ROWS * HB_STRIDE + F16_ROWS * 8 + LOGIT_FLOATS) * 4;
     constexpr int PERM_OFF = 2 * PLANE_BYTES > HEAD_BYTES ? 2 * PLANE_BYTES : HEAD_BYTES;     // behind both uses of the buffer
     int *s_perm = reinterpret_cast<int *>(smem16 + PERM_OFF);    // [256] GEMM row -> board-cell row
 
@@ -399,8 +468,12 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
             for (int mt = 0; mt < MT; ++mt) {
                 const int r = s_perm[wr * (MT * 32) + mt * 32 + r32];
                 const int b = r / CELLS, pos = r % CELLS, y = pos / COLS, x = pos % COLS;
-                u64 bm = 0, bt = 0;
-                if (r < TB * CELLS && board0 + b < n_leaf) { const int slot = leaf_slot[board0 + b]; bm = mine[(size_t)slot * bstride]; bt = theirs[(size_t)slot * bstride]; }
+                typename G::B bm = board_zero<G::W>(), bt = board_zero<G::W>();
+                if (r < TB * CELLS && board0 + b < n_leaf) {
+                    const int slot = leaf_slot[board0 + b];
+                    bm = board_load_strided<G::W>(mine, slot, bstride);
+                    bt = board_load_strided<G::W>(theirs, slot, bstride);
+                }
                 h8 ah;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -409,7 +482,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
                     float val = 0.0f;
                     if (kk < 27 && ((vmask[mt] >> tap) & 1u)) {
                         const int bit = G::bit_of(y + tap / 3 - 1, x + tap % 3 - 1);
-                        const int mi = (int)((bm >> bit) & 1ull), th = (int)((bt >> bit) & 1ull);
+                        const int mi = board_bit(bm, bit) ? 1 : 0, th = board_bit(bt, bit) ? 1 : 0;
                         val = (pl == 0 ? (1 - mi) * (1 - th) : (pl == 1 ? mi : th)) ? ACT_SCALE : 0.0f;
                     }
                     ah[j] = (_Float16)val;
@@ -431,6 +504,8 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     // above 128 channels a tap's weights for one column tile (SL x 8 registers) no longer fit beside the accumulators and the
     // residual: those nets stream them two slabs ahead (conv16: same order of sums per output -- taps, then slabs, ascending)
     constexpr bool WIDE = CT > 4;
+    // weight slabs in flight in the ring form (a divisor of SL)
+    constexpr int WIDE_PD = SL % 4 == 0 ? 4 : (SL % 5 == 0 ? 5 : (SL % 7 == 0 ? 7 : 2));
     h8 wh[3][2], wl[3][2];
     if constexpr (STATIC16) {
 #pragma unroll
@@ -457,8 +532,12 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
             conv16s<G, MT, 9, SL, CT>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
                                       abyte, vmask, need, ROW_BYTES, ZERO_BYTE + half * 16, lane);
         else
-            conv16<G, MT, 9, SL, CT, ABL>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
-                                          abyte, vmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+            if constexpr (WIDE && MT < 4 && (ABL & 7) == 0)
+                conv16r<G, MT, 9, SL, CT, WIDE_PD>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
+                                                   abyte, vmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+            else
+                conv16<G, MT, 9, SL, CT, ABL>(acc, P.conv_w + (size_t)layer * P.conv_w_stride + (size_t)wc * 2 * 64, plane_hi, PLANE_BYTES,
+                                              abyte, vmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
         if (layer < 16) STAMP16(3 + 3 * layer);
         __syncthreads();
         if (layer < 16) STAMP16(4 + 3 * layer);
@@ -509,54 +588,126 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     STAMP16(53);
 
     // ---- Linear layers, masked softmax, tanh: identical to the fp32 kernel --------------------------------
-    if (tid < TB * CELLS) {
-        const int pos = tid % CELLS;
-        float pa[8];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) pa[o] = 0.0f;
-        const float *hrow = hb + tid * HB_STRIDE;
-        for (int c = 0; c < POL_CH; ++c) {
-            const float h = hrow[c];
-            const float4 w0 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8);
-            const float4 w1 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8 + 4);
-            pa[0] = fmaf(h, w0.x, pa[0]); pa[1] = fmaf(h, w0.y, pa[1]); pa[2] = fmaf(h, w0.z, pa[2]); pa[3] = fmaf(h, w0.w, pa[3]);
-            pa[4] = fmaf(h, w1.x, pa[4]); pa[5] = fmaf(h, w1.y, pa[5]); pa[6] = fmaf(h, w1.z, pa[6]);
-        }
-        float pv = 0.0f;
-#pragma unroll
-        for (int c = 0; c < VAL_CH; ++c) pv = fmaf(hrow[POL_CH + c], P.fcv_w[c * CELLS + pos], pv);
-        pa[7] = pv;
-#pragma unroll
-        for (int o = 0; o < 8; ++o) part[tid * 8 + o] = pa[o];
-    }
-    __syncthreads();
     float *logits = part + F16_ROWS * 8;
-    if (tid < TB * 8) {
-        const int b = tid >> 3, o = tid & 7;
-        float sum = 0.0f;
-        for (int pos = 0; pos < CELLS; ++pos) sum += part[(b * CELLS + pos) * 8 + o];
-        logits[tid] = sum + (o < 7 ? (o < A ? P.fcp_b[o] : 0.0f) : P.fcv_b[0]);
-    }
-    __syncthreads();
-    // masked softmax + tanh on eight lanes per board, as in the fp32 kernel (one lane per action, the eighth holds the value
-    // logit; the denominator is summed in action order)
-    if (tid < TB * 8) {
-        const int b = tid >> 3, a = tid & 7;
-        const bool liveb = board0 + b < n_leaf;
-        const int slot = liveb ? leaf_slot[board0 + b] : 0;
-        const uint32_t legal = liveb ? G::legal_mask(mine[(size_t)slot * bstride], theirs[(size_t)slot * bstride]) : 0u;
-        const bool leg = a < A && ((legal >> a) & 1u);
-        const float x = logits[b * 8 + a];
-        float mx = leg ? x : -INFINITY;
+    if constexpr (A <= 7) {
+        for (int cell = tid; cell < TB * CELLS; cell += NTHREADS) {      // one thread per board cell (a second pass for narrow wave grids)
+            const int pos = cell % CELLS;
+            float pa[8];
 #pragma unroll
-        for (int m = 1; m < 8; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 8));
-        const float ex = leg ? expf(x - mx) : 0.0f;
-        float den = 0.0f;
+            for (int o = 0; o < 8; ++o) pa[o] = 0.0f;
+            const float *hrow = hb + cell * HB_STRIDE;
+            for (int c = 0; c < POL_CH; ++c) {
+                const float h = hrow[c];
+                const float4 w0 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8);
+                const float4 w1 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8 + 4);
+                pa[0] = fmaf(h, w0.x, pa[0]); pa[1] = fmaf(h, w0.y, pa[1]); pa[2] = fmaf(h, w0.z, pa[2]); pa[3] = fmaf(h, w0.w, pa[3]);
+                pa[4] = fmaf(h, w1.x, pa[4]); pa[5] = fmaf(h, w1.y, pa[5]); pa[6] = fmaf(h, w1.z, pa[6]);
+            }
+            float pv = 0.0f;
 #pragma unroll
-        for (int k = 0; k < A; ++k) den += __shfl(ex, k, 8);
-        if (liveb) {
-            out_p[(size_t)slot * p_stride + a] = leg ? ex / den : 0.0f;
-            if (a == 7) out_v[(size_t)slot * v_stride] = tanhf(x);
+            for (int c = 0; c < VAL_CH; ++c) pv = fmaf(hrow[POL_CH + c], P.fcv_w[c * CELLS + pos], pv);
+            pa[7] = pv;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) part[cell * 8 + o] = pa[o];
+        }
+        __syncthreads();
+        if (tid < TB * 8) {
+            const int b = tid >> 3, o = tid & 7;
+            float sum = 0.0f;
+            for (int pos = 0; pos < CELLS; ++pos) sum += part[(b * CELLS + pos) * 8 + o];
+            logits[tid] = sum + (o < 7 ? (o < A ? P.fcp_b[o] : 0.0f) : P.fcv_b[0]);
+        }
+        __syncthreads();
+        // masked softmax + tanh on eight lanes per board, as in the fp32 kernel (one lane per action, the eighth holds the value
+        // logit; the denominator is summed in action order)
+        if (tid < TB * 8) {
+            const int b = tid >> 3, a = tid & 7;
+            const bool liveb = board0 + b < n_leaf;
+            const int slot = liveb ? leaf_slot[board0 + b] : 0;
+            const typename G::B bmine = board_load_strided<G::W>(mine, slot, bstride), btheirs = board_load_strided<G::W>(theirs, slot, bstride);
+            const bool leg = liveb && a < A && G::legal(bmine, btheirs, a);
+            const float x = logits[b * 8 + a];
+            float mx = leg ? x : -INFINITY;
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 8));
+            const float ex = leg ? expf(x - mx) : 0.0f;
+            float den = 0.0f;
+#pragma unroll
+            for (int k = 0; k < A; ++k) den += __shfl(ex, k, 8);
+            if (liveb) {
+                out_p[(size_t)slot * p_stride + a] = leg ? ex / den : 0.0f;
+                if (a == 7) out_v[(size_t)slot * v_stride] = tanhf(x);
+            }
+        }
+    } else {
+        // wide action spaces (Gomoku: 81), as in the fp32 kernel: the 32 input channels of an output are cut into KS slices (a
+        // slice walks its CELLS inputs per channel in flatten order), one thread per (slice, board, output), weights stored
+        // [input][AP]; the slices are added in order after the barrier; then one wave per board, two actions per lane.
+        constexpr int AP = G::AP, NOUT = TB * (A + 1);        // per board: A policy logits + the value logit
+        constexpr int KSMAX = NTHREADS / NOUT;
+        constexpr int KS = KSMAX >= 8 ? 8 : (KSMAX >= 4 ? 4 : (KSMAX >= 2 ? 2 : 1));
+        constexpr int CS = POL_CH / KS;
+        static_assert(KS * NOUT <= F16_ROWS * 8 && A <= 128 && AP <= 128 && TB <= WAVES, "partial sums fit; one wave per board");
+        float *vl = logits + TB * AP;
+#pragma unroll 1
+        for (int t = tid; t < KS * NOUT; t += NTHREADS) {
+            const int ks = t / NOUT, item = t % NOUT, b = item / (A + 1), o = item % (A + 1);
+            float sum = 0.0f;
+            if (o < A) {
+#pragma unroll 1
+                for (int c = ks * CS; c < (ks + 1) * CS; ++c) {
+                    const float *ap = hb + (size_t)b * CELLS * HB_STRIDE + c;
+                    const float *wp = P.fcp_w + (size_t)c * CELLS * AP + o;
+#pragma unroll 9
+                    for (int pos = 0; pos < CELLS; ++pos) sum = fmaf(ap[pos * HB_STRIDE], wp[(size_t)pos * AP], sum);
+                }
+            } else if (ks == 0) {
+#pragma unroll 1
+                for (int c = 0; c < VAL_CH; ++c)
+#pragma unroll 3
+                    for (int pos = 0; pos < CELLS; ++pos)
+                        sum = fmaf(hb[(b * CELLS + pos) * HB_STRIDE + POL_CH + c], P.fcv_w[c * CELLS + pos], sum);
+            }
+            part[t] = sum;
+        }
+        __syncthreads();
+        for (int item = tid; item < NOUT; item += NTHREADS) {
+            const int b = item / (A + 1), o = item % (A + 1);
+            float sum = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) sum += part[ks * NOUT + item];
+            if (o < A) logits[b * AP + o] = sum + P.fcp_b[o];
+            else vl[b] = sum + P.fcv_b[0];
+        }
+        __syncthreads();
+        const int b = tid >> 6;
+        if (b < TB && board0 + b < n_leaf) {
+            const int slot = leaf_slot[board0 + b];
+            const typename G::B bmine = board_load_strided<G::W>(mine, slot, bstride), btheirs = board_load_strided<G::W>(theirs, slot, bstride);
+            const float *lg = logits + b * AP;
+            float x[2], ex[2];
+            bool leg[2];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int a = lane + 64 * i;
+                leg[i] = a < A && G::legal(bmine, btheirs, a);
+                x[i] = a < A ? lg[a] : 0.0f;
+                if (leg[i]) mx = fmaxf(mx, x[i]);
+            }
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+            ex[0] = leg[0] ? expf(x[0] - mx) : 0.0f;
+            ex[1] = leg[1] ? expf(x[1] - mx) : 0.0f;
+            float den = ex[0] + ex[1];
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) den += __shfl_xor(den, m, 64);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int a = lane + 64 * i;
+                if (a < AP) out_p[(size_t)slot * p_stride + a] = leg[i] ? ex[i] / den : 0.0f;
+            }
+            if (lane == 0) out_v[(size_t)slot * v_stride] = tanhf(vl[b]);
         }
     }
     STAMP16(55);
@@ -626,11 +777,14 @@ static void build_row_order16(int WR, int32_t *perm) {
 }
 
 ResNet16Dev *resnet16_create(int game, int blocks, int channels) {
-    if (game != 0 || blocks < 0 || channels <= 0) return nullptr;
+    if ((game != 0 && game != 2) || blocks < 0 || channels <= 0) return nullptr;      // Connect-4, Gomoku 9x9
     const int CT = (channels + 31) / 32;
     if (CT < 1 || CT > 8) return nullptr;      // up to 256 channels (two fp16 planes of 128 rows x 264 halves: 136 KB of LDS)
     ResNet16Dev *n = new ResNet16Dev();
-    n->CT = CT; n->C = channels; n->blocks = blocks; n->cells = Connect4::CELLS; n->A = Connect4::A;
+    n->game = game; n->CT = CT; n->C = channels; n->blocks = blocks;
+    n->cells = game == 0 ? Connect4::CELLS : Gomoku9::CELLS;
+    n->A = game == 0 ? Connect4::A : Gomoku9::A;
+    n->AS = game == 0 ? 8 : Gomoku9::AP;
     const int SL = 2 * CT, CP = 32 * CT;
     size_t off = 0;
     auto reserve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -644,8 +798,8 @@ ResNet16Dev *resnet16_create(int game, int blocks, int channels) {
     n->o_conv_b = reserve((size_t)CP * 4 * 2 * blocks + 4);
     n->o_pol_b = reserve(32 * 4);
     n->o_val_b = reserve(32 * 4);
-    n->o_fcp_w = reserve((size_t)POL_CH * n->cells * 8 * 4);
-    n->o_fcp_b = reserve(8 * 4);
+    n->o_fcp_w = reserve((size_t)POL_CH * n->cells * n->AS * 4);
+    n->o_fcp_b = reserve((size_t)n->AS * 4);
     n->o_fcv_w = reserve((size_t)VAL_CH * n->cells * 4);
     n->o_fcv_b = reserve(4 * 4);
     n->o_up = reserve((size_t)(2 * blocks + 1) * 4);
@@ -719,7 +873,7 @@ int resnet16_load(ResNet16Dev *n, const float *blob, size_t n_floats, hipStream_
         for (int c2 = 0; c2 < POL_CH; ++c2)
             for (int pos = 0; pos < n->cells; ++pos)
                 for (int o = 0; o < n->A; ++o)
-                    F(n->o_fcp_w)[((size_t)c2 * n->cells + pos) * 8 + o] = fw[(size_t)o * POL_CH * n->cells + (size_t)c2 * n->cells + pos];
+                    F(n->o_fcp_w)[((size_t)c2 * n->cells + pos) * n->AS + o] = fw[(size_t)o * POL_CH * n->cells + (size_t)c2 * n->cells + pos];
         for (int o = 0; o < n->A; ++o) F(n->o_fcp_b)[o] = fb[o];
     }
     {
@@ -738,15 +892,15 @@ int resnet16_load(ResNet16Dev *n, const float *blob, size_t n_floats, hipStream_
     return 0;
 }
 
-template <int CT, int WR, int ABL = 0, int NR = 256>
+template <class G, int CT, int WR, int ABL = 0, int NR = 256>
 static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, int bstride, const int32_t *leaf_slot, const int32_t *n_leaf,
                      int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s,
                      hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
-    using G = Connect4;
     constexpr int F16_ROWS = NR;
     constexpr int WAVES = WR * CT, RS = 32 * CT + 8, TB = F16_ROWS / G::CELLS;
     constexpr size_t planes = (size_t)2 * (F16_ROWS + 1) * RS * 2;
-    constexpr size_t heads = ((size_t)F16_ROWS * HB_STRIDE + F16_ROWS * 8 + TB * 8) * 4;
+    constexpr size_t heads = ((size_t)F16_ROWS * HB_STRIDE + F16_ROWS * 8 + (G::A <= 7 ? TB * 8 : TB * (G::AP + 8))) * 4;
+    static_assert((planes > heads ? planes : heads) + F16_ROWS * sizeof(int32_t) <= 160 * 1024, "LDS of one workgroup");
     const size_t lds = (planes > heads ? planes : heads) + F16_ROWS * sizeof(int32_t);   // + the row-order table
     // the attribute is per device and idempotent: a racing second call sets the same value
     static std::atomic<unsigned long long> attr_done{0};
@@ -763,17 +917,27 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, i
     const int grid = (cap + TB - 1) / TB;
     Net16Params Q = P;
     Q.perm = P.perm + (size_t)(WR == 1 ? 0 : WR == 2 ? 1 : WR == 4 ? 2 : 3) * 256;           // row order of this wave grid (NR = 256 only)
-    Q.wg_flops = P.wg_flops * (NR / 256.0) * (NR == 256 ? 1.0 : 6.0 / 5.0);                   // (the smaller forms skip no taps)
+    Q.wg_flops = P.tower_row_flops * NR * (NR == 256 ? 5.0 / 6.0 : 1.0) + P.rest_board_flops * TB;      // (only the six-board row order skips taps)
     hipExtLaunchKernelGGL((k_resnet_forward_f16<G, CT, WR, ABL, NR>), dim3(grid), dim3(64 * WAVES), lds, s, ev_start, ev_stop, 0, Q, mine, theirs,
                           bstride, leaf_slot, n_leaf, out_p, out_v, p_stride, v_stride);
 }
 
-// Every workgroup of this kernel holds 6 boards (252 of 256 GEMM rows) in the tap-skipping row order and issues three fp16
-// MFMAs (hi*hi, hi*lo, lo*hi) per fp32 multiply-add of the tower.
-double resnet16_wg_flops(const ResNet16Dev *n, double flops_per_board) {
+// Executed fp16 MFMA FLOP: three MFMAs (hi*hi, hi*lo, lo*hi) per fp32 multiply-add, over the GEMM rows and padded channels a
+// workgroup really computes.  tower_row: the tower per GEMM row; rest: stem + heads per board.
+static void flops16(const ResNet16Dev *n, double flops_per_board, double *tower_row, double *rest_board) {
     const double C = n->C, cells = n->cells, CP = 32.0 * n->CT;
     const double tower = 2.0 * cells * 2.0 * n->blocks * C * C * 9;
-    return 3.0 * (tower * (256.0 / cells) * (5.0 / 6.0) * (CP / C) * (CP / C) + (flops_per_board - tower) * 6.0);
+    *tower_row = 3.0 * tower / cells * (CP / C) * (CP / C);
+    *rest_board = 3.0 * (flops_per_board - tower);
+}
+// per board, for the form a launch of this capacity takes (Connect-4 <= 128 channels, large batches: six boards on 256 rows
+// in the tap-skipping row order; three boards on 128 rows; one board on 64; Gomoku: one board on 96 rows)
+double resnet16_exec_flops_per_board(const ResNet16Dev *n, double flops_per_board, int max_leaves) {
+    double tr, rb;
+    flops16(n, flops_per_board, &tr, &rb);
+    if (n->game != 0) return tr * 96.0 + rb;
+    if (n->CT > 4) return max_leaves <= 256 ? tr * 64.0 + rb : tr * 128.0 / 3.0 + rb;
+    return tr * 256.0 * (5.0 / 6.0) / 6.0 + rb;
 }
 
 // what a launch needs besides the network parameters
@@ -786,10 +950,10 @@ struct Fwd16 {
     int p_stride, v_stride;
     hipStream_t s;
 };
-template <int CT, int WR, int NR = 256, int ABL = 0>
+template <int CT, int WR, int NR = 256, int ABL = 0, class G = Connect4>
 static void go16(Net16Params &P, const Fwd16 &a, int gate_lo, int gate_hi, hipEvent_t e0, hipEvent_t e1) {
     P.gate = (gate_lo / 16) | ((gate_hi / 16) << 16);              // run only for list lengths in (lo, hi]; hi = 0: no upper end
-    launch16<CT, WR, ABL, NR>(P, a.mine, a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.max_leaves, a.out_p, a.p_stride, a.out_v, a.v_stride,
+    launch16<G, CT, WR, ABL, NR>(P, a.mine, a.theirs, a.bstride, a.leaf_slot, a.n_leaf, a.max_leaves, a.out_p, a.p_stride, a.out_v, a.v_stride,
                               a.s, e0, e1);
     P.gate = 0;
 }
@@ -845,8 +1009,8 @@ static void forward_wide(Net16Params &P, const Fwd16 &a, bool by_count, hipEvent
 
 void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32_t *leaf_slot, const int32_t *n_leaf,
                       int max_leaves, float *out_p, int p_stride, float *out_v, int v_stride, hipStream_t s, bool by_count,
-                      double *flop_acc, double wg_flops, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    Fwd16 a{leaf0, leaf0 + Connect4::W, bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, p_stride, v_stride, s};
+                      double *flop_acc, double flops_per_board, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    Fwd16 a{leaf0, leaf0 + (n->game == 0 ? Connect4::W : Gomoku9::W), bstride, leaf_slot, n_leaf, max_leaves, out_p, out_v, p_stride, v_stride, s};
     Net16Params P;
     unsigned char *d = n->d_blob;
     auto H = [&](size_t o) { return reinterpret_cast<const h8 *>(d + o); };
@@ -860,8 +1024,22 @@ void resnet16_forward(ResNet16Dev *n, const u64 *leaf0, int bstride, const int32
     P.perm = n->d_perm;
     P.dbg = nullptr;
     P.flop_acc = flop_acc;
-    P.wg_flops = wg_flops;
+    P.wg_flops = 0.0;
+    flops16(n, flops_per_board, &P.tower_row_flops, &P.rest_board_flops);
     P.gate = 0;
+    if (n->game == 2) {      // Gomoku 9x9: one board (81 cells) on 96 GEMM rows, one row group of CT waves; any list length
+        switch (n->CT) {
+            case 1: go16<1, 1, 96, 0, Gomoku9>(P, a, 0, 0, ev_start, ev_stop); break;
+            case 2: go16<2, 1, 96, 0, Gomoku9>(P, a, 0, 0, ev_start, ev_stop); break;
+            case 3: go16<3, 1, 96, 0, Gomoku9>(P, a, 0, 0, ev_start, ev_stop); break;
+            case 4: go16<4, 1, 96, 0, Gomoku9>(P, a, 0, 0, ev_start, ev_stop); break;
+            case 5: go16<5, 1, 96, 0, Gomoku9>(P, a, 0, 0, ev_start, ev_stop); break;
+            case 6: go16<6, 1, 96, 0, Gomoku9>(P, a, 0, 0, ev_start, ev_stop); break;
+            case 7: go16<7, 1, 96, 0, Gomoku9>(P, a, 0, 0, ev_start, ev_stop); break;
+            default: go16<8, 1, 96, 0, Gomoku9>(P, a, 0, 0, ev_start, ev_stop); break;
+        }
+        return;
+    }
     // wave grid WR x CT over the 256-row x C tile (tuning knob AZSP_F16_WR: forces the six-board form on that grid)
     static const int wr_env = [] { const char *e = getenv("AZSP_F16_WR"); return e ? atoi(e) : 0; }();
     switch (n->CT) {

@@ -223,10 +223,10 @@ def main() -> None:
     ap.add_argument("--no-eval-cache", action="store_true", help="skip the evaluation-cache measurements")
     ap.add_argument("--eval-cache-headline", action="store_true", help="diagnostics: make the evaluation-cache run the top-level line")
     ap.add_argument("--game", choices=["connect4", "gomoku9"], default="connect4",
-                    help="gomoku9 = BASELINE.json configs[4]'s game (not a headline config; fp32 only, no CPU baseline)")
+                    help="gomoku9 = BASELINE.json configs[4]'s game (not a headline config; no CPU baseline, no evaluation cache)")
     args = ap.parse_args()
     if args.game == "gomoku9":
-        args.single, args.no_cpu_baseline, args.precision = True, True, "f32"
+        args.no_cpu_baseline = True
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

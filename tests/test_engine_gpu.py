@@ -296,7 +296,7 @@ def test_baseline_networks_within_north_star_tolerance(azsp, game, blocks, ch):
     pt, vt, mask = _torch_reference(net, rules, boards)
     from azsp.weights import resnet_blob
     blob = resnet_blob(net)[0]
-    for f16 in ((False, True) if game == "connect4" else (False,)):
+    for f16 in (False, True):
         with _engine(azsp, game, 64, 1, res_blocks=blocks, channels=ch, f16_split=f16) as e:
             e.load_resnet(blob)
             p, v = e.predict(np.stack(boards))
@@ -306,12 +306,14 @@ def test_baseline_networks_within_north_star_tolerance(azsp, game, blocks, ch):
         assert np.all(p[mask == 0] == 0)
 
 
+@pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
 @pytest.mark.parametrize("blocks,ch", [(2, 32), (2, 64), (2, 96), (3, 128), (1, 192), (2, 256)])
-def test_gomoku_network_geometries_against_torch(azsp, blocks, ch):
+def test_gomoku_network_geometries_against_torch(azsp, blocks, ch, f16):
     """Every Gomoku kernel geometry -- three boards per workgroup up to 64 channels; from 96 on one board per workgroup on
     five 16-row MFMA tiles plus the corner cell on the vector ALU (chunks of 6 or 8 sixteen-channel groups), Linear layer in
-    channel slices, value conv in channel slices, softmax on a wave -- against the module's float32 PyTorch forward, with
-    non-trivial BatchNorm statistics; batch sizes that leave workgroups partly filled and empty."""
+    channel slices, value conv in channel slices, softmax on a wave; the split-fp16 kernel's one-board form on 96 GEMM rows
+    with one to eight column tiles -- against the module's float32 PyTorch forward, with non-trivial BatchNorm statistics;
+    batch sizes that leave workgroups partly filled and empty."""
     import torch
     from azsp.weights import resnet_blob
     torch.manual_seed(100 * blocks + ch)
@@ -331,12 +333,12 @@ def test_gomoku_network_geometries_against_torch(azsp, blocks, ch):
     boards.append(full)                                           # one legal move: the corner cell
     pt, vt, mask = _torch_reference(net, rules, boards)
     blob = resnet_blob(net)[0]
-    with _engine(azsp, "gomoku9", 64, 1, res_blocks=blocks, channels=ch) as e:
+    with _engine(azsp, "gomoku9", 64, 1, res_blocks=blocks, channels=ch, f16_split=f16) as e:
         e.load_resnet(blob)
         p, v = e.predict(np.stack(boards))
         p1, v1 = e.predict(np.stack(boards[:7]))                  # bits do not depend on the batch
     err_p, err_v = np.max(np.abs(p - pt)), np.max(np.abs(v - vt))
-    print(f"[net-error] gomoku9 {blocks}x{ch}: max |dp| = {err_p:.2e}, max |dv| = {err_v:.2e} vs torch f32")
+    print(f"[net-error] gomoku9 {blocks}x{ch} f16x2={f16}: max |dp| = {err_p:.2e}, max |dv| = {err_v:.2e} vs torch f32")
     assert err_p < NET_TOL_WIDE and err_v < NET_TOL_WIDE
     assert np.all(p[mask == 0] == 0) and p[-1][80] == 1.0
     assert np.array_equal(p[:7], p1) and np.array_equal(v[:7], v1)
@@ -486,20 +488,22 @@ def test_full_size_config5_one_gpu_shard_properties(azsp):
     _full_size_invariants(azsp, azsp.GomokuGame(), oz.G9Rules(), net, 192, 200, 5, n_groups=2)
 
 
-def test_config5_network_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp):
-    """configs[4]'s network (10 blocks x 256 channels, 9x9) in the loop at oracle size: 6 games x 24 sims."""
+@pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
+def test_config5_network_self_play_bit_exact_vs_oracle_fed_by_device_net(azsp, f16):
+    """configs[4]'s network (10 blocks x 256 channels, 9x9) in the loop at oracle size: 6 games x 24 sims (exact fp32 and
+    the split-fp16 kernel: the oracle is fed by the same device kernel, so the search must agree bit for bit)."""
     import torch
     from azsp.weights import resnet_blob
     torch.manual_seed(9)
     net = azsp.ResNet((9, 9), 81, 10, 256).eval()
     blob, blocks, ch = resnet_blob(net)
     n, sims, seed = 6, 24, 8
-    with _engine(azsp, "gomoku9", 64, 1, res_blocks=blocks, channels=ch) as pe:
+    with _engine(azsp, "gomoku9", 64, 1, res_blocks=blocks, channels=ch, f16_split=f16) as pe:
         pe.load_resnet(blob)
         cb = co.make_predict_cb(lambda bs: pe.predict(np.stack(bs)), (9, 9), 81)
         ref = co.generate("gomoku9", sims, n, seed=seed, predict_cb=cb, trace=False)
     np.random.seed(seed)
-    gen = azsp.EpisodeGenerator(game=azsp.GomokuGame(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1))
+    gen = azsp.EpisodeGenerator(game=azsp.GomokuGame(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), f16_split=f16)
     eps = list(gen.generate_episodes(net))
     assert float(np.random.random_sample()) == ref["next_uniform"]
     _assert_equals_c_oracle(eps, ref, n)

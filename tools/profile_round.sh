@@ -58,7 +58,7 @@ python3 "$R/bench.py" --slots 1 --steps 5 --warmup 1 --no-cpu-baseline --no-cloc
 python3 "$R/bench.py" --blocks 8 --channels 128 --no-cpu-baseline > "$OUT/${TAG}_config4_bench.json" 2> "$OUT/${TAG}_config4_bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_config4_trace" -- python3 "$R/bench.py" --blocks 8 --channels 128 --single --no-eval-cache --no-cpu-baseline --steps 1 --warmup 0 > "$OUT/${TAG}_config4_trace.log" 2>&1
 keep_stats "${TAG}_config4_trace" "${TAG}_config4_kernel_stats.csv"
-python3 "$R/bench.py" --game gomoku9 --blocks 10 --channels 256 --sims 200 --slots 512 --single --no-cpu-baseline --steps 1 --warmup 1 > "$OUT/${TAG}_config5_bench.json" 2> "$OUT/${TAG}_config5_bench.err"
+python3 "$R/bench.py" --game gomoku9 --blocks 10 --channels 256 --sims 200 --slots 512 --no-cpu-baseline --steps 1 --warmup 1 > "$OUT/${TAG}_config5_bench.json" 2> "$OUT/${TAG}_config5_bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_config5_trace" -- python3 "$R/bench.py" --game gomoku9 --blocks 10 --channels 256 --sims 200 --slots 512 --single --no-cpu-baseline --steps 1 --warmup 0 > "$OUT/${TAG}_config5_trace.log" 2>&1
 keep_stats "${TAG}_config5_trace" "${TAG}_config5_kernel_stats.csv"
 fi
