@@ -42,6 +42,7 @@ constexpr int F16_ROWS = 256;
 constexpr int ACT_SHIFT = 4;            // activations are stored scaled by 2^4
 constexpr float ACT_SCALE = 16.0f;
 constexpr int HB_STRIDE = 37;           // floats per row of the head-activation buffer (odd: conflict-free column reads)
+constexpr int TB_STRIDE = 33;           // floats per row of the value conv's per-tap partial sums
 
 struct Net16Params {
     const h8 *stem_w, *conv_w, *pol_w, *val_w;
@@ -271,6 +272,40 @@ __device__ __forceinline__ void conv16s(f32x16 (&acc)[NTILE], const h8 *__restri
     }
 }
 
+// Both head convolutions in ONE pass over the activations.  The policy conv is 1x1 (32 channels).  The value conv is 3x3
+// with 3 output channels: as a 3x3 conv on a 32-wide column tile it would run 9 taps x 32 columns for 27 useful dot products
+// per cell; it is computed as the 1x1 conv  T[cell][tap * 3 + c] = sum_k act[cell][k] * Wv[c][k][tap]  (27 of 32 columns) and
+// the nine taps are added per cell from the neighbours' T afterwards (value_from_taps in the kernel): a ninth of the MFMAs.
+//   wp, wt : [slab][plane][64 lanes] h8 (permute_split with one tap, one column tile)
+template <class G, int NTILE, int SL>
+__device__ __forceinline__ void head_pair16(f32x16 (&accp)[NTILE], f32x16 (&acct)[NTILE], const h8 *__restrict__ wp, const h8 *__restrict__ wt,
+                                            const unsigned char *plane_hi, int plane_bytes, const int (&abyte)[NTILE],
+                                            const uint32_t (&vmask)[NTILE], int zero_byte, int lane) {
+    const unsigned char *ar[NTILE];
+#pragma unroll
+    for (int i = 0; i < NTILE; ++i) ar[i] = plane_hi + (((vmask[i] >> 4) & 1u) ? abyte[i] : zero_byte);      // the cell's own row
+    h8 ph = wp[lane], pl = wp[64 + lane], th = wt[lane], tl = wt[64 + lane];
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+        const h8 cph = ph, cpl = pl, cth = th, ctl = tl;
+        if (sl + 1 < SL) {
+            const h8 *a = wp + (size_t)(sl + 1) * 2 * 64 + lane, *b = wt + (size_t)(sl + 1) * 2 * 64 + lane;
+            ph = a[0]; pl = a[64]; th = b[0]; tl = b[64];
+        }
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i) {
+            const h8 ah = *reinterpret_cast<const h8 *>(ar[i] + sl * 32);
+            const h8 al = *reinterpret_cast<const h8 *>(ar[i] + sl * 32 + plane_bytes);
+            accp[i] = mfma16(ah, cph, accp[i]);
+            accp[i] = mfma16(ah, cpl, accp[i]);
+            accp[i] = mfma16(al, cph, accp[i]);
+            acct[i] = mfma16(ah, cth, acct[i]);
+            acct[i] = mfma16(ah, ctl, acct[i]);
+            acct[i] = mfma16(al, cth, acct[i]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // statically scheduled tower layer for the 2 x CT wave grid (4 row tiles x one column tile per wave)
 // ------------------------------------------------------------------------------------------------
@@ -379,10 +414,12 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     _Float16 *act_lo = reinterpret_cast<_Float16 *>(smem16 + PLANE_BYTES);
     float *hb = reinterpret_cast<float *>(smem16);               // after the tower: [256][HB_STRIDE] head activations
     float *part = hb + F16_ROWS * HB_STRIDE;                     // [256][8], then the logits: [TB][8], or [TB][AP] + [TB] value logits
+    float *tbuf = part;                                          // before that: [256][TB_STRIDE] per-tap value partials (head_pair16)
     constexpr int LOGIT_FLOATS = A <= 7 ? TB * 8 : TB * (G::AP + 8);
-    constexpr int HEAD_BYTES = (F16_ROWS * HB_STRIDE + F16_ROWS * 8 + LOGIT_FLOATS) * 4;
+    constexpr int HEAD_BYTES = (F16_ROWS * HB_STRIDE + (F16_ROWS * TB_STRIDE > F16_ROWS * 8 + LOGIT_FLOATS ? F16_ROWS * TB_STRIDE : F16_ROWS * 8 + LOGIT_FLOATS)) * 4;
     constexpr int PERM_OFF = 2 * PLANE_BYTES > HEAD_BYTES ? 2 * PLANE_BYTES : HEAD_BYTES;     // behind both uses of the buffer
     int *s_perm = reinterpret_cast<int *>(smem16 + PERM_OFF);    // [256] GEMM row -> board-cell row
+    u64 *s_board = reinterpret_cast<u64 *>(smem16 + PERM_OFF + F16_ROWS * 4);      // [TB][2][W]: the workgroup's positions (zero beyond the list)
 
     const int n_leaf = *n_leaf_p;
     const int board0 = blockIdx.x * TB;
@@ -399,7 +436,19 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
 
     for (int i = tid; i < RS; i += NTHREADS) { act_hi[F16_ROWS * RS + i] = (_Float16)0; act_lo[F16_ROWS * RS + i] = (_Float16)0; }
     for (int i = tid; i < F16_ROWS; i += NTHREADS) s_perm[i] = NR == 256 ? P.perm[i] : i;
+    // the positions come in beside the row order (one dependent chain list entry -> bitboards instead of one per stem tile
+    // behind the row order's)
+    if (tid < TB * 2 * G::W) {
+        const int b = tid / (2 * G::W), k = tid % (2 * G::W);
+        u64 word = 0;
+        if (board0 + b < n_leaf) {
+            const int slot = leaf_slot[board0 + b];
+            word = (k < G::W ? mine : theirs)[(size_t)slot * bstride + k % G::W];
+        }
+        s_board[tid] = word;
+    }
     __syncthreads();
+    STAMP16(1);
 
     auto row_geom = [&](int g, uint32_t &vm, int &ab, int &r) {     // g = GEMM row; r = its board-cell row in LDS
         r = s_perm[g];
@@ -455,49 +504,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         }
     };
 
-    // ---- stem: A fragments straight from the bitboards (values 0 / 2^ACT_SHIFT: lo plane is zero) ------
-    {
-        const f32x16 bias = channel_vec16(P.stem_b + ch0, half);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = bias;
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            const h8 *wp = P.stem_w + ((size_t)sl * CT + wc) * 2 * 64 + lane;
-            const h8 bh = wp[0], bl = wp[64];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int r = s_perm[wr * (MT * 32) + mt * 32 + r32];
-                const int b = r / CELLS, pos = r % CELLS, y = pos / COLS, x = pos % COLS;
-                typename G::B bm = board_zero<G::W>(), bt = board_zero<G::W>();
-                if (r < TB * CELLS && board0 + b < n_leaf) {
-                    const int slot = leaf_slot[board0 + b];
-                    bm = board_load_strided<G::W>(mine, slot, bstride);
-                    bt = board_load_strided<G::W>(theirs, slot, bstride);
-                }
-                h8 ah;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int kk = 16 * sl + 8 * half + j;          // K index = tap*3 + plane
-                    const int tap = kk / 3, pl = kk % 3;
-                    float val = 0.0f;
-                    if (kk < 27 && ((vmask[mt] >> tap) & 1u)) {
-                        const int bit = G::bit_of(y + tap / 3 - 1, x + tap % 3 - 1);
-                        const int mi = board_bit(bm, bit) ? 1 : 0, th = board_bit(bt, bit) ? 1 : 0;
-                        val = (pl == 0 ? (1 - mi) * (1 - th) : (pl == 1 ? mi : th)) ? ACT_SCALE : 0.0f;
-                    }
-                    ah[j] = (_Float16)val;
-                }
-                acc[mt] = mfma16(ah, bh, acc[mt]);
-                acc[mt] = mfma16(ah, bl, acc[mt]);
-            }
-        }
-        store_act(acc, P.stem_inv, true);
-    }
-    __syncthreads();
-    STAMP16(2);
-    if constexpr ((ABL & 8) != 0) { if (tid == 0) P.dbg[(size_t)blockIdx.x * 64 + 56] = __builtin_amdgcn_s_memtime(); }   // core-clock counter
-
-    // ---- residual blocks ---------------------------------------------------------------------------------
+    // ---- the tower's forms, and its first weights (requested before the stem: an L2 round trip off the tower's start) ----
     // 64 channels on the 2 x 2 wave grid: the statically scheduled tower (nine taps per layer, so the two weight
     // buffers swap roles from layer to layer: the layer's parity is a template parameter)
     constexpr bool STATIC16 = (ABL & 7) == 0 && NR == 256 && WR == 2 && (CT == 2 || CT == 4);
@@ -515,6 +522,54 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
             wl[sl / 2][sl & 1] = wp[64];
         }
     }
+
+    // ---- stem: A fragments straight from the bitboards (values 0 / 2^ACT_SHIFT: lo plane is zero) ------
+    {
+        const f32x16 bias = channel_vec16(P.stem_b + ch0, half);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = bias;
+        // the 27 binary inputs of a row (K index kk = tap * 3 + plane; planes: empty, mine, theirs) as one bit mask, taps
+        // static; a lane then needs bits 16 sl + 8 half + j of it
+        uint32_t inb[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int r = lrow[mt];
+            const int b = r / CELLS, pos = r % CELLS, y = pos / COLS, x = pos % COLS;
+            typename G::B bm = board_zero<G::W>(), bt = board_zero<G::W>();
+            if (r < TB * CELLS) {
+#pragma unroll
+                for (int k = 0; k < G::W; ++k) { bm.w[k] = s_board[b * 2 * G::W + k]; bt.w[k] = s_board[b * 2 * G::W + G::W + k]; }
+            }
+            uint32_t m = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int bit = G::bit_of(y + t / 3 - 1, x + t % 3 - 1);
+                const uint32_t mi = board_bit(bm, bit) ? 1u : 0u, th = board_bit(bt, bit) ? 1u : 0u;
+                const uint32_t three = ((mi | th) ^ 1u) | (mi << 1) | (th << 2);
+                m |= ((vmask[mt] >> t) & 1u) ? three << (3 * t) : 0u;
+            }
+            inb[mt] = m >> (8 * half);
+        }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const h8 *wp = P.stem_w + ((size_t)sl * CT + wc) * 2 * 64 + lane;
+            const h8 bh = wp[0], bl = wp[64];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                h8 ah;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ah[j] = ((inb[mt] >> (16 * sl + j)) & 1u) ? (_Float16)ACT_SCALE : (_Float16)0;
+                acc[mt] = mfma16(ah, bh, acc[mt]);
+                acc[mt] = mfma16(ah, bl, acc[mt]);
+            }
+        }
+        store_act(acc, P.stem_inv, true);
+    }
+    __syncthreads();
+    STAMP16(2);
+    if constexpr ((ABL & 8) != 0) { if (tid == 0) P.dbg[(size_t)blockIdx.x * 64 + 56] = __builtin_amdgcn_s_memtime(); }   // core-clock counter
+
+    // ---- residual blocks ---------------------------------------------------------------------------------
     for (int layer = 0; layer < 2 * P.blocks; ++layer) {
         const bool second = layer & 1;
         const f32x16 bias = channel_vec16(P.conv_b + (size_t)layer * P.conv_b_stride + ch0, half);
@@ -549,29 +604,25 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     if constexpr ((ABL & 8) != 0) {
         if (tid == 0) { P.dbg[(size_t)blockIdx.x * 64 + 57] = __builtin_amdgcn_s_memtime(); P.dbg[(size_t)blockIdx.x * 64 + 58] = wall_clock64(); }
     }
-    // ---- heads: policy 1x1 and value 3x3 convs, one 32-wide column tile each; the row tiles of a row
-    //      group are dealt round-robin to its CT waves -----------------------------------------------------
-    f32x16 accp[PT], accv[PT];
+    // ---- heads: policy 1x1 conv and the value 3x3 conv as a 27-column 1x1 conv (head_pair16), one 32-wide column tile
+    //      each; the row tiles of a row group are dealt round-robin to its CT waves --------------------------------
+    f32x16 accp[PT], acct[PT];
     int hbyte[PT], hrow0[PT], hrow[PT];
-    uint32_t hmask[PT], hneed[PT];
+    uint32_t hmask[PT];
     {
-        const f32x16 bp = channel_vec16(P.pol_b, half), bv = channel_vec16(P.val_b, half);
+        const f32x16 bp = channel_vec16(P.pol_b, half);
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
             const int mt = wc + i * CT;
             hrow0[i] = mt < MT ? wr * (MT * 32) + mt * 32 : -1;
             row_geom(hrow0[i] < 0 ? F16_ROWS - 1 : hrow0[i] + r32, hmask[i], hbyte[i], hrow[i]);
             if (hrow0[i] < 0) hmask[i] = 0;
-            hneed[i] = need_of(hmask[i]);
             accp[i] = bp;
-            accv[i] = bv;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acct[i][v] = 0.0f;
         }
     }
-    if constexpr (WIDE) conv16<G, PT, 1, SL, 1>(accp, P.pol_w, plane_hi, PLANE_BYTES, hbyte, hmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
-    else conv16s<G, PT, 1, SL, 1>(accp, P.pol_w, plane_hi, PLANE_BYTES, hbyte, hmask, hneed, ROW_BYTES, ZERO_BYTE + half * 16, lane);
-    STAMP16(51);
-    if constexpr (WIDE) conv16<G, PT, 9, SL, 1>(accv, P.val_w, plane_hi, PLANE_BYTES, hbyte, hmask, ROW_BYTES, ZERO_BYTE + half * 16, lane);
-    else conv16s<G, PT, 9, SL, 1>(accv, P.val_w, plane_hi, PLANE_BYTES, hbyte, hmask, hneed, ROW_BYTES, ZERO_BYTE + half * 16, lane);
+    head_pair16<G, PT, SL>(accp, acct, P.pol_w, P.val_w, plane_hi, PLANE_BYTES, hbyte, hmask, ZERO_BYTE + half * 16, lane);
     STAMP16(52);
     __syncthreads();
 #pragma unroll
@@ -581,9 +632,21 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
             for (int v = 0; v < 16; ++v) {
                 const int ch = cd_ch16(v, lane);                          // the lane's cell is row hrow[i]
                 hb[hrow[i] * HB_STRIDE + ch] = fmaxf(accp[i][v] * P.pol_inv, 0.0f);
-                if (ch < VAL_CH) hb[hrow[i] * HB_STRIDE + POL_CH + ch] = fmaxf(accv[i][v] * P.val_inv, 0.0f);
+                tbuf[hrow[i] * TB_STRIDE + ch] = acct[i][v];
             }
         }
+    __syncthreads();
+    // value_from_taps: value[cell][c] = relu((bias[c] + sum over the on-board taps, ascending, of T[neighbour][tap * 3 + c]) * inv)
+    for (int item = tid; item < TB * CELLS * VAL_CH; item += NTHREADS) {
+        const int r = item / VAL_CH, c = item % VAL_CH, pos = r % CELLS, y = pos / COLS, x = pos % COLS;
+        float sum = P.val_b[c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy >= 0 && yy < ROWS && xx >= 0 && xx < COLS) sum += tbuf[(r + (t / 3 - 1) * COLS + (t % 3 - 1)) * TB_STRIDE + t * VAL_CH + c];
+        }
+        hb[r * HB_STRIDE + POL_CH + c] = fmaxf(sum * P.val_inv, 0.0f);
+    }
     __syncthreads();
     STAMP16(53);
 
@@ -880,7 +943,11 @@ int resnet16_load(ResNet16Dev *n, const float *blob, size_t n_floats, hipStream_
         ConvBN c = take_conv_bn(p, VAL_CH, C, 3);
         fold(c, w, b);
         const int k = pow2_scale_for(w);
-        permute_split(w, VAL_CH, C, 9, SL, 1, k, H(n->o_val_w));
+        std::vector<float> w1((size_t)9 * VAL_CH * C);          // [o2 = tap * 3 + c][input channel]: the 3x3 conv as a 27-column 1x1 conv
+        for (int t = 0; t < 9; ++t)
+            for (int c2 = 0; c2 < VAL_CH; ++c2)
+                for (int i = 0; i < C; ++i) w1[((size_t)(t * VAL_CH + c2)) * C + i] = w[((size_t)c2 * C + i) * 9 + t];
+        permute_split(w1, 9 * VAL_CH, C, 1, SL, 1, k, H(n->o_val_w));
         for (int o = 0; o < VAL_CH; ++o) F(n->o_val_b)[o] = b[o] * ldexpf(1.0f, ACT_SHIFT + k);
         n->val_inv = ldexpf(1.0f, -(ACT_SHIFT + k));
         const float *fw = take(p, (size_t)VAL_CH * n->cells), *fb = take(p, 1);
@@ -899,9 +966,10 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, i
     constexpr int F16_ROWS = NR;
     constexpr int WAVES = WR * CT, RS = 32 * CT + 8, TB = F16_ROWS / G::CELLS;
     constexpr size_t planes = (size_t)2 * (F16_ROWS + 1) * RS * 2;
-    constexpr size_t heads = ((size_t)F16_ROWS * HB_STRIDE + F16_ROWS * 8 + (G::A <= 7 ? TB * 8 : TB * (G::AP + 8))) * 4;
-    static_assert((planes > heads ? planes : heads) + F16_ROWS * sizeof(int32_t) <= 160 * 1024, "LDS of one workgroup");
-    const size_t lds = (planes > heads ? planes : heads) + F16_ROWS * sizeof(int32_t);   // + the row-order table
+    constexpr size_t logit_floats = G::A <= 7 ? TB * 8 : TB * (G::AP + 8);
+    constexpr size_t heads = ((size_t)F16_ROWS * HB_STRIDE + ((size_t)F16_ROWS * TB_STRIDE > F16_ROWS * 8 + logit_floats ? (size_t)F16_ROWS * TB_STRIDE : F16_ROWS * 8 + logit_floats)) * 4;
+    static_assert((planes > heads ? planes : heads) + F16_ROWS * sizeof(int32_t) + TB * 2 * G::W * 8 <= 160 * 1024, "LDS of one workgroup");
+    const size_t lds = (planes > heads ? planes : heads) + F16_ROWS * sizeof(int32_t) + TB * 2 * G::W * 8;   // + the row-order table and the positions
     // the attribute is per device and idempotent: a racing second call sets the same value
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
