@@ -479,8 +479,8 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     f32x16 acc[MT], xres[MT];
     const int ch0 = wc * 32;                                      // first output channel of this wave's column tile
 
-    // writes relu(acc*inv) as split fp16 planes (scaled by 2^ACT_SHIFT); optionally keeps the fp32 copy.  inv is a power
-    // of two, so scaling by inv * 2^ACT_SHIFT first and taking the fp32 copy back by 2^-ACT_SHIFT rounds nowhere.
+    // writes relu(acc*inv) as split fp16 planes (scaled by 2^ACT_SHIFT); optionally keeps the fp32 copy, in the same scale
+    // (inv is a power of two, so scaling rounds nowhere; the block's second convolution starts from residual * up / 2^ACT_SHIFT).
     auto store_act = [&](const f32x16 (&a)[MT], float inv, bool keep) {
         const float inv_s = inv * ACT_SCALE;
 #pragma unroll
@@ -491,9 +491,9 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
                 f32x4v as;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float t = fmaxf(a[mt][4 * i + j] * inv_s, 0.0f);
-                    if (keep) xres[mt][4 * i + j] = t * (1.0f / ACT_SCALE);
-                    as[j] = fminf(t, 65504.0f);
+                    const float t = __builtin_amdgcn_fmed3f(a[mt][4 * i + j] * inv_s, 0.0f, 65504.0f);      // ReLU and the fp16 range in one
+                    if (keep) xres[mt][4 * i + j] = t;               // (the residual stays in the planes' scale: see `up` below)
+                    as[j] = t;
                 }
                 const h4 hi = __builtin_convertvector(as, h4);
                 const h4 lo = __builtin_convertvector(as - __builtin_convertvector(hi, f32x4v), h4);
@@ -573,7 +573,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     for (int layer = 0; layer < 2 * P.blocks; ++layer) {
         const bool second = layer & 1;
         const f32x16 bias = channel_vec16(P.conv_b + (size_t)layer * P.conv_b_stride + ch0, half);
-        const float up = P.conv_up[layer];
+        const float up = P.conv_up[layer] * (1.0f / ACT_SCALE);      // the residual is kept scaled by 2^ACT_SHIFT
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
