@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <string>
 #include <utility>
+#include <chrono>
 #include <vector>
 
 #include "../../include/azsp.h"
@@ -450,7 +451,20 @@ static int search_enqueue(azsp_engine *e, int n_act) {
     return 0;
 }
 
-static int search(azsp_engine *e, int n_act) { return search_enqueue(e, n_act); }
+// (diagnostics, AZSP_PROBE_VERBOSE: host time spent enqueuing searches, printed when the engine is destroyed -- whether
+//  the host or the GPU sets the pace of a launch-bound configuration)
+static double g_enqueue_s = 0.0;
+static uint64_t g_enqueue_rounds = 0;
+static int search(azsp_engine *e, int n_act) {
+    static const bool verbose = getenv("AZSP_PROBE_VERBOSE") != nullptr;
+    if (!verbose) return search_enqueue(e, n_act);
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint64_t r0 = e->rounds_host;
+    const int rc = search_enqueue(e, n_act);
+    g_enqueue_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    g_enqueue_rounds += e->rounds_host - r0;
+    return rc;
+}
 
 // A new generation run, new weights or another evaluator: every cached row is void.  (Cleared on the main stream, which
 // every search forks from.)
@@ -520,6 +534,9 @@ size_t azsp_resnet_blob_floats(int32_t game, int32_t res_blocks, int32_t channel
 
 void azsp_destroy(azsp_engine *e) {
     if (!e) return;
+    if (g_enqueue_rounds && getenv("AZSP_PROBE_VERBOSE"))
+        fprintf(stderr, "[azsp host] %.3f s enqueuing %llu simulation rounds: %.1f us of host time per round\n", g_enqueue_s,
+                (unsigned long long)g_enqueue_rounds, 1e6 * g_enqueue_s / (double)g_enqueue_rounds);
     DeviceScope _dev_scope(e->cfg.device);
     for (int k = 0; k < MAX_GROUPS; ++k) if (e->gstream[k]) (void)hipStreamSynchronize(e->gstream[k]);
     for (auto &p : e->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
