@@ -67,7 +67,8 @@ enum { AZSP_OK = 0, AZSP_ERR_ARG = -1, AZSP_ERR_HIP = -2, AZSP_ERR_STATE = -3, A
 #define AZSP_FLAG_TIMING 1u      /* record HIP events around every kernel class (azsp_get_stats) */
 #define AZSP_FLAG_F16_SPLIT 2u   /* device ResNet on the fp16 matrix pipe with every fp32 operand split into
                                     two fp16 numbers (hi*hi + hi*lo + lo*hi, fp32 accumulate): fp32-class
-                                    accuracy (<= 1e-5 on p, v), 3 MFMAs at 16x the fp32-MFMA rate.  Without
+                                    accuracy (<= 1e-5 on p, v), 3 MFMAs at 16x the fp32-MFMA rate.  Connect-4
+                                    and Gomoku 9x9, up to 256 channels (azsp_create fails otherwise).  Without
                                     the flag the network runs on v_mfma_f32_32x32x2_f32 (exact fp32).     */
 
 #define AZSP_FLAG_TREE_REUSE 4u  /* NOT in the reference (it rebuilds every tree every ply, monte_carlo_tree_search.py:116-123;
