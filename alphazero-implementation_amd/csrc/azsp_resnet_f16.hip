@@ -143,6 +143,7 @@ __device__ __forceinline__ void conv16(f32x16 (&acc)[NTILE], const h8 *__restric
                 acc[i] = mfma16(ah, bh, acc[i]);
                 acc[i] = mfma16(ah, bl, acc[i]);
                 acc[i] = mfma16(al, bh, acc[i]);
+                if constexpr (CT > 4) __builtin_amdgcn_sched_barrier(0);      // wide nets' three-board form: pinned order (4 x 256, 3072 boards: 3.60 -> 3.15 ms); the six-board forms lose with it
             }
         }
 #pragma unroll
@@ -176,7 +177,7 @@ __device__ __forceinline__ void conv16r(f32x16 (&acc)[NTILE], const h8 *__restri
         return w + ((size_t)qq * CT) * 2 * 64 + lane;
     };
     // A fragments: a ring of AR register pairs, the pair of step j + AD requested at step j (a step = one row tile of one slab)
-    constexpr int STEPS = SL * NTILE, AR = STEPS % 4 == 0 ? 4 : 2, AD = AR / 2;
+    constexpr int STEPS = SL * NTILE, AR = STEPS % 4 == 0 ? 4 : 2, AD = AR - 1;
     const unsigned char *arow[NTILE], *arow_n[NTILE];
 #pragma unroll
     for (int i = 0; i < NTILE; ++i) arow[i] = arow_of(0, i);
@@ -210,6 +211,7 @@ __device__ __forceinline__ void conv16r(f32x16 (&acc)[NTILE], const h8 *__restri
                 acc[i] = mfma16(ah, bh, acc[i]);
                 acc[i] = mfma16(ah, bl, acc[i]);
                 acc[i] = mfma16(al, bh, acc[i]);
+                __builtin_amdgcn_sched_barrier(0);      // keep the requests ahead of the MFMAs (the compiler moves them back to their uses)
             }
         }
 #pragma unroll
