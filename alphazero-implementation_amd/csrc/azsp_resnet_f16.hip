@@ -238,6 +238,8 @@ __device__ __forceinline__ void conv16s(f32x16 (&acc)[NTILE], const h8 *__restri
     };
     constexpr bool DB = SL <= 4;            // double-buffer only while the registers last (<= 64 channels; with more slabs the second
                                             // buffer spills even in the one-board form: 9 x 128 launch 0.256 -> 0.367 ms)
+    // (Without the second buffer the tap's last tile reloading each slab's pair with the next tap's right after its last use was
+    //  measured too: slower, 9 x 128 one board 225 -> 268 us.)
     if constexpr (DB) load_b(0, nh, nl);
     for (int tap = 0; tap < TAPS; ++tap) {
         const int t9 = (TAPS == 9) ? tap : 4;
@@ -262,13 +264,23 @@ __device__ __forceinline__ void conv16s(f32x16 (&acc)[NTILE], const h8 *__restri
 #pragma unroll
         for (int i = 0; i < NTILE; ++i) {
             if (!((need[i] >> t9) & 1u)) continue;
+            // the tile's fragments two slabs ahead of their MFMAs, order pinned
+            h8 xh[3], xl[3];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                xh[k] = *reinterpret_cast<const h8 *>(ar[i] + k * 32);
+                xl[k] = *reinterpret_cast<const h8 *>(ar[i] + k * 32 + plane_bytes);
+            }
 #pragma unroll
             for (int sl = 0; sl < SL; ++sl) {
-                const h8 ah = *reinterpret_cast<const h8 *>(ar[i] + sl * 32);
-                const h8 al = *reinterpret_cast<const h8 *>(ar[i] + sl * 32 + plane_bytes);
-                acc[i] = mfma16(ah, bh[sl], acc[i]);
-                acc[i] = mfma16(ah, bl[sl], acc[i]);
-                acc[i] = mfma16(al, bh[sl], acc[i]);
+                if (sl + 2 < SL) {
+                    xh[(sl + 2) % 3] = *reinterpret_cast<const h8 *>(ar[i] + (sl + 2) * 32);
+                    xl[(sl + 2) % 3] = *reinterpret_cast<const h8 *>(ar[i] + (sl + 2) * 32 + plane_bytes);
+                }
+                acc[i] = mfma16(xh[sl % 3], bh[sl], acc[i]);
+                acc[i] = mfma16(xh[sl % 3], bl[sl], acc[i]);
+                acc[i] = mfma16(xl[sl % 3], bh[sl], acc[i]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
