@@ -345,12 +345,13 @@ def test_gomoku_network_geometries_against_torch(azsp, blocks, ch, f16):
 
 
 @pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
-@pytest.mark.parametrize("blocks,ch", [(4, 64), (2, 128), (2, 32)])
+@pytest.mark.parametrize("blocks,ch", [(4, 64), (2, 128), (2, 32), (1, 192), (2, 256)])
 def test_resnet_every_batch_regime_returns_the_same_bits(azsp, blocks, ch, f16):
     """The engine picks a kernel variant by batch size (<= 768 boards: 3 boards per workgroup; above: 6 boards per
     workgroup with the rows in tap-skipping order, other wave grids).  A position's (P, V) must not depend on it:
     the same boards through a small batch, a large batch and a large batch in another order are compared bitwise
-    (this is what makes the tap-skipping order and the MFMA value head testable: they are exact rearrangements)."""
+    (this is what makes the tap-skipping order and the MFMA value head testable: they are exact rearrangements).
+    192 / 256 channels: the split-fp16 kernel's one-board form (64 rows, ring pipeline) against its three-board form."""
     import torch
     from azsp.weights import resnet_blob
     torch.manual_seed(ch + blocks)
@@ -383,7 +384,8 @@ def test_resnet_every_batch_regime_returns_the_same_bits(azsp, blocks, ch, f16):
     pt, vt, _ = _torch_reference(net, rules, list(boards[:64]))    # and all of it is the network (tolerance as elsewhere)
     err_p, err_v = np.max(np.abs(p_big[:64] - pt)), np.max(np.abs(v_big[:64] - vt))
     print(f"[net-error] connect4 {blocks}x{ch} f16x2={f16} (all batch regimes): max |dp| = {err_p:.2e}, max |dv| = {err_v:.2e}")
-    assert err_p < NET_TOL and err_v < NET_TOL
+    tol = NET_TOL if ch <= 128 else NET_TOL_WIDE
+    assert err_p < tol and err_v < tol
 
 
 # ------------------------------------------------------------------------------------ full size
