@@ -1150,6 +1150,24 @@ def test_eval_cache_identical_episodes_at_2048x100_and_fewer_evaluations(azsp, f
     assert abs(again - first) <= 0.01 * first      # (two slot groups meeting one new position in one search both evaluate it)
 
 
+@pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
+def test_eval_cache_identical_episodes_with_a_wide_network(azsp, f16):
+    """The same at 192 channels, where the evaluation cache's launches (gated by the list's length on the device) switch
+    between the one-board and the three-board forms of the wide nets: 600 games x 30 sims in one slot group, cache off / on."""
+    import torch
+    torch.manual_seed(3)
+    net = azsp.ResNet((6, 7), 7, 1, 192).eval()
+    n, sims = 600, 30
+    off, s_off, r_off = _run_gen(azsp, net, n, sims, 11, f16_split=f16)
+    np.random.seed(11)
+    g = azsp.EpisodeGenerator(game=azsp.Connect4Game(), config=azsp.AlphaZeroConfig(32, 1, sims, n, 1, 1), f16_split=f16, eval_cache=True,
+                              n_groups=1)
+    on = list(g.generate_episodes(net))
+    s_on, r_on = g.last_stats, float(np.random.random_sample())
+    assert on == off and r_on == r_off
+    assert s_on["evals"] == s_off["evals"] and s_on["evals_executed"] < 0.7 * s_on["evals"]
+
+
 def test_eval_cache_edge_cases(azsp):
     """A table far too small for the run (fills up: later positions fall back to their slots' private entries), boards
     without a key (a floating stone: MCTS.run_batch accepts anything), tree reuse on top, new weights on a live
