@@ -480,14 +480,16 @@ def _assert_equals_c_oracle(eps, ref, n):
         assert [s.value for s in ep.samples] == ref["values"][lo:hi].tolist()
 
 
-def test_full_size_config5_one_gpu_shard_properties(azsp):
+@pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
+def test_full_size_config5_one_gpu_shard_properties(azsp, f16):
     """BASELINE.json configs[4] on one GPU: 9x9 Gomoku through the Game plugin, 256-ch/10-block ResNet, 200 sims/move;
     192 concurrent games in two slot groups (a shard sized for the test's time budget), checked through the
-    size-independent invariants (pi * sims integral, move chains, outcome / z consistency, evaluation accounting)."""
+    size-independent invariants (pi * sims integral, move chains, outcome / z consistency, evaluation accounting);
+    both inference kernels."""
     import torch
     torch.manual_seed(0)
     net = azsp.ResNet((9, 9), 81, 10, 256)
-    _full_size_invariants(azsp, azsp.GomokuGame(), oz.G9Rules(), net, 192, 200, 5, n_groups=2)
+    _full_size_invariants(azsp, azsp.GomokuGame(), oz.G9Rules(), net, 192, 200, 5, n_groups=2, f16_split=f16)
 
 
 @pytest.mark.parametrize("f16", [False, True], ids=["f32", "f16x2"])
