@@ -430,10 +430,11 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     float *part = hb + F16_ROWS * HB_STRIDE;                     // [256][8], then the logits: [TB][8], or [TB][AP] + [TB] value logits
     float *tbuf = part;                                          // before that: [256][TB_STRIDE] per-tap value partials (head_pair16)
     constexpr int LOGIT_FLOATS = A <= 7 ? TB * 8 : TB * (G::AP + 8);
-    constexpr int HEAD_BYTES = (F16_ROWS * HB_STRIDE + (F16_ROWS * TB_STRIDE > F16_ROWS * 8 + LOGIT_FLOATS ? F16_ROWS * TB_STRIDE : F16_ROWS * 8 + LOGIT_FLOATS)) * 4;
+    constexpr int HEAD_BYTES = (F16_ROWS * HB_STRIDE + F16_ROWS * TB_STRIDE + LOGIT_FLOATS) * 4;      // (the Linear layer's partial sums reuse the tap buffer)
     constexpr int PERM_OFF = 2 * PLANE_BYTES > HEAD_BYTES ? 2 * PLANE_BYTES : HEAD_BYTES;     // behind both uses of the buffer
     int *s_perm = reinterpret_cast<int *>(smem16 + PERM_OFF);    // [256] GEMM row -> board-cell row
     u64 *s_board = reinterpret_cast<u64 *>(smem16 + PERM_OFF + F16_ROWS * 4);      // [TB][2][W]: the workgroup's positions (zero beyond the list)
+    int *s_slot = reinterpret_cast<int *>(s_board + TB * 2 * G::W);                // [TB]: their slots
 
     const int n_leaf = *n_leaf_p;
     const int board0 = blockIdx.x * TB;
@@ -458,6 +459,7 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         if (board0 + b < n_leaf) {
             const int slot = leaf_slot[board0 + b];
             word = (k < G::W ? mine : theirs)[(size_t)slot * bstride + k % G::W];
+            if (k == 0) s_slot[b] = slot;
         }
         s_board[tid] = word;
     }
@@ -665,34 +667,54 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
     STAMP16(53);
 
     // ---- Linear layers, masked softmax, tanh: identical to the fp32 kernel --------------------------------
-    float *logits = part + F16_ROWS * 8;
+    float *logits = part + F16_ROWS * TB_STRIDE;
     if constexpr (A <= 7) {
-        for (int cell = tid; cell < TB * CELLS; cell += NTHREADS) {      // one thread per board cell (a second pass for narrow wave grids)
-            const int pos = cell % CELLS;
-            float pa[8];
+        // Linear layers: thread (channel slice ks of KS, cell pos) takes its 32 / KS policy channels for ALL the workgroup's boards
+        // -- a weight row is loaded once per workgroup, not once per board --, slice 0 the three value channels too; partial sums
+        // [ks][board][pos][8] over the dead tap buffer; then thread (board, output, ks) adds its 42 cells and the KS slices of an
+        // output meet in neighbouring lanes (fixed order).
+        constexpr int KS = 4, CS = POL_CH / KS;
+        static_assert(KS * TB * CELLS * 8 <= F16_ROWS * TB_STRIDE && KS * TB * 8 <= NTHREADS, "partial sums fit the tap buffer");
+        for (int item = tid; item < KS * CELLS; item += NTHREADS) {
+            const int ks = item / CELLS, pos = item % CELLS;
+            float pa[TB][8];
 #pragma unroll
-            for (int o = 0; o < 8; ++o) pa[o] = 0.0f;
-            const float *hrow = hb + cell * HB_STRIDE;
-            for (int c = 0; c < POL_CH; ++c) {
-                const float h = hrow[c];
+            for (int b = 0; b < TB; ++b)
+#pragma unroll
+                for (int o = 0; o < 8; ++o) pa[b][o] = 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < CS; ++cc) {
+                const int c = ks * CS + cc;
                 const float4 w0 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8);
                 const float4 w1 = *reinterpret_cast<const float4 *>(P.fcp_w + ((size_t)c * CELLS + pos) * 8 + 4);
-                pa[0] = fmaf(h, w0.x, pa[0]); pa[1] = fmaf(h, w0.y, pa[1]); pa[2] = fmaf(h, w0.z, pa[2]); pa[3] = fmaf(h, w0.w, pa[3]);
-                pa[4] = fmaf(h, w1.x, pa[4]); pa[5] = fmaf(h, w1.y, pa[5]); pa[6] = fmaf(h, w1.z, pa[6]);
+#pragma unroll
+                for (int b = 0; b < TB; ++b) {
+                    const float h = hb[(b * CELLS + pos) * HB_STRIDE + c];
+                    pa[b][0] = fmaf(h, w0.x, pa[b][0]); pa[b][1] = fmaf(h, w0.y, pa[b][1]); pa[b][2] = fmaf(h, w0.z, pa[b][2]); pa[b][3] = fmaf(h, w0.w, pa[b][3]);
+                    pa[b][4] = fmaf(h, w1.x, pa[b][4]); pa[b][5] = fmaf(h, w1.y, pa[b][5]); pa[b][6] = fmaf(h, w1.z, pa[b][6]);
+                }
             }
-            float pv = 0.0f;
+            if (ks == 0) {
 #pragma unroll
-            for (int c = 0; c < VAL_CH; ++c) pv = fmaf(hrow[POL_CH + c], P.fcv_w[c * CELLS + pos], pv);
-            pa[7] = pv;
+                for (int c = 0; c < VAL_CH; ++c) {
+                    const float wv = P.fcv_w[c * CELLS + pos];
 #pragma unroll
-            for (int o = 0; o < 8; ++o) part[cell * 8 + o] = pa[o];
+                    for (int b = 0; b < TB; ++b) pa[b][7] = fmaf(hb[(b * CELLS + pos) * HB_STRIDE + POL_CH + c], wv, pa[b][7]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TB; ++b)
+#pragma unroll
+                for (int o = 0; o < 8; ++o) part[((ks * TB + b) * CELLS + pos) * 8 + o] = pa[b][o];
         }
         __syncthreads();
-        if (tid < TB * 8) {
-            const int b = tid >> 3, o = tid & 7;
+        if (tid < TB * 8 * KS) {
+            const int ks = tid % KS, o = (tid / KS) & 7, b = tid / (8 * KS);
             float sum = 0.0f;
-            for (int pos = 0; pos < CELLS; ++pos) sum += part[(b * CELLS + pos) * 8 + o];
-            logits[tid] = sum + (o < 7 ? (o < A ? P.fcp_b[o] : 0.0f) : P.fcv_b[0]);
+            for (int pos = 0; pos < CELLS; ++pos) sum += part[((ks * TB + b) * CELLS + pos) * 8 + o];
+            sum += __shfl_xor(sum, 1, KS);
+            sum += __shfl_xor(sum, 2, KS);
+            if (ks == 0) logits[b * 8 + o] = sum + (o < 7 ? (o < A ? P.fcp_b[o] : 0.0f) : P.fcv_b[0]);
         }
         __syncthreads();
         // masked softmax + tanh on eight lanes per board, as in the fp32 kernel (one lane per action, the eighth holds the value
@@ -700,8 +722,10 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         if (tid < TB * 8) {
             const int b = tid >> 3, a = tid & 7;
             const bool liveb = board0 + b < n_leaf;
-            const int slot = liveb ? leaf_slot[board0 + b] : 0;
-            const typename G::B bmine = board_load_strided<G::W>(mine, slot, bstride), btheirs = board_load_strided<G::W>(theirs, slot, bstride);
+            const int slot = liveb ? s_slot[b] : 0;
+            typename G::B bmine, btheirs;
+#pragma unroll
+            for (int k = 0; k < G::W; ++k) { bmine.w[k] = s_board[b * 2 * G::W + k]; btheirs.w[k] = s_board[b * 2 * G::W + G::W + k]; }
             const bool leg = liveb && a < A && G::legal(bmine, btheirs, a);
             const float x = logits[b * 8 + a];
             float mx = leg ? x : -INFINITY;
@@ -759,8 +783,10 @@ void k_resnet_forward_f16(Net16Params P, const u64 *__restrict__ mine, const u64
         __syncthreads();
         const int b = tid >> 6;
         if (b < TB && board0 + b < n_leaf) {
-            const int slot = leaf_slot[board0 + b];
-            const typename G::B bmine = board_load_strided<G::W>(mine, slot, bstride), btheirs = board_load_strided<G::W>(theirs, slot, bstride);
+            const int slot = s_slot[b];
+            typename G::B bmine, btheirs;
+#pragma unroll
+            for (int k = 0; k < G::W; ++k) { bmine.w[k] = s_board[b * 2 * G::W + k]; btheirs.w[k] = s_board[b * 2 * G::W + G::W + k]; }
             const float *lg = logits + b * AP;
             float x[2], ex[2];
             bool leg[2];
@@ -981,9 +1007,9 @@ static void launch16(const Net16Params &P, const u64 *mine, const u64 *theirs, i
     constexpr int WAVES = WR * CT, RS = 32 * CT + 8, TB = F16_ROWS / G::CELLS;
     constexpr size_t planes = (size_t)2 * (F16_ROWS + 1) * RS * 2;
     constexpr size_t logit_floats = G::A <= 7 ? TB * 8 : TB * (G::AP + 8);
-    constexpr size_t heads = ((size_t)F16_ROWS * HB_STRIDE + ((size_t)F16_ROWS * TB_STRIDE > F16_ROWS * 8 + logit_floats ? (size_t)F16_ROWS * TB_STRIDE : F16_ROWS * 8 + logit_floats)) * 4;
-    static_assert((planes > heads ? planes : heads) + F16_ROWS * sizeof(int32_t) + TB * 2 * G::W * 8 <= 160 * 1024, "LDS of one workgroup");
-    const size_t lds = (planes > heads ? planes : heads) + F16_ROWS * sizeof(int32_t) + TB * 2 * G::W * 8;   // + the row-order table and the positions
+    constexpr size_t heads = ((size_t)F16_ROWS * HB_STRIDE + (size_t)F16_ROWS * TB_STRIDE + logit_floats) * 4;
+    static_assert((planes > heads ? planes : heads) + F16_ROWS * sizeof(int32_t) + TB * 2 * G::W * 8 + TB * 4 <= 160 * 1024, "LDS of one workgroup");
+    const size_t lds = (planes > heads ? planes : heads) + F16_ROWS * sizeof(int32_t) + TB * 2 * G::W * 8 + TB * 4;   // + the row-order table, the positions, their slots
     // the attribute is per device and idempotent: a racing second call sets the same value
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
