@@ -1,3 +1,4 @@
+"""Throughput of the first-generation surface (azsp.gen1: search + episode generation on the connect package's states)."""
 import sys, time
 sys.path.insert(0, "alphazero-implementation_amd")
 import numpy as np, torch

@@ -1,3 +1,4 @@
+"""cProfile of the Python side of one generate_episodes step (what the host spends while the GPU searches)."""
 import os, sys, time, cProfile, pstats
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,3 +1,5 @@
+"""The engine loop alone (search / play, no episode fetch, no Python objects) against the full generator: is the host the limit?
+    python tools/nomat.py [--cache] [--f16]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,3 +1,5 @@
+"""Phase trace (AZSP_RESNET_TRACE stamps) and in-kernel clock of both inference kernels at one batch size:
+    python tools/phase_trace.py [boards]"""
 import os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "alphazero-implementation_amd"))

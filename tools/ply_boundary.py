@@ -1,3 +1,5 @@
+"""Kernels around the ply boundaries of a rocprofv3 --kernel-trace csv (what runs between two searches):
+    python tools/ply_boundary.py <kernel_trace.csv>"""
 import csv, sys
 rows=[]
 with open(sys.argv[1]) as f:

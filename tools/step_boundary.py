@@ -1,3 +1,5 @@
+"""Kernels around the step (generate_episodes call) boundaries of a rocprofv3 --kernel-trace csv:
+    python tools/step_boundary.py <kernel_trace.csv>"""
 import csv, sys
 rows=[]
 with open(sys.argv[1]) as f:

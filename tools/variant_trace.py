@@ -1,3 +1,5 @@
+"""Phase trace of ONE inference-kernel variant (mean microseconds per phase over the workgroups, in-kernel clock):
+    python tools/variant_trace.py <boards> <variant name, e.g. c4_64_mid | c4_64_one | c4_64_big> [f16]"""
 import os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "alphazero-implementation_amd"))
